@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by RUNNING the reference's own Python (build container only).
+
+The reference lives at /root/reference (read-only) and never travels to the GPU box;
+only the vectors written here do.  Nothing in this script is copied from the
+reference: modules are imported (with stub modules for uninstalled third-party
+imports) and single functions of un-importable scripts are compiled from their own
+file with ``ast`` at run time.
+
+    python oracle/gen_golden.py            # writes tests/golden/
+"""
+import ast
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference/src"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from oracle import seeded  # noqa: E402
+
+np.float = float  # numpy-2 shim for src/DA/grl.py:64
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+# third-party modules the reference imports at top level but that are absent here
+_stub("soundfile")
+_stub("librosa")
+_stub("dcase_util")
+_stub("dcase_util.data", DecisionEncoder=object)
+# data.config allocates 2.6 GB at import: hand the constants in instead
+_cfg = _stub("data.config", sr=32000, hop_size=255, pooling_time_ratio=4, max_learning_rate=0.0005,
+             max_len_seconds=10.0)
+import data  # noqa: E402  (namespace package of the reference)
+data.config = _cfg
+
+from models.CRNN_GRL import CRNN, Predictor, Clip_Discriminator  # noqa: E402
+from DA.cdan_frame import ConditionalDomainAdversarialLoss  # noqa: E402
+from utilities.utils import weights_init  # noqa: E402
+from utilities import ramps  # noqa: E402
+from utilities.ManyHotEncoder import ManyHotEncoder  # noqa: E402
+from oracle.crnn_oracle import CRNN_KWARGS, PREDICTOR_KWARGS  # noqa: E402
+from oracle.labels_oracle import BIRD_LIST  # noqa: E402
+
+
+def ref_function(path, name, glb):
+    """Compile ONE function of a reference script that cannot be imported as a module."""
+    tree = ast.parse(open(path).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name]
+    code = compile(ast.Module(body=fn, type_ignores=[]), path, "exec")
+    exec(code, glb)
+    return glb[name]
+
+
+_glb = dict(torch=torch, np=np, cfg=_cfg)
+update_ema_variables = ref_function(os.path.join(REF, "main_baseline.py"), "update_ema_variables", _glb)
+adjust_learning_rate = ref_function(os.path.join(REF, "main_baseline.py"), "adjust_learning_rate", _glb)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def build(dropout, seed):
+    kw = dict(CRNN_KWARGS)
+    kw["dropout"] = dropout
+    crnn, pred = CRNN(**kw), Predictor(**PREDICTOR_KWARGS)
+    v1 = seeded.load_seeded(crnn, seed)
+    v2 = seeded.load_seeded(pred, seed + 1)
+    return crnn, pred, seeded.checksum(v1), seeded.checksum(v2)
+
+
+def named_grads(mods):
+    out = {}
+    for pfx, m in mods:
+        for k, p in m.named_parameters():
+            out[pfx + k] = p.grad.detach().numpy().copy()
+    return out
+
+
+def small_tensors(named, limit=4096):
+    return {k: v for k, v in named.items() if v.size <= limit}
+
+
+def crnn_case(tag, B, T, seed, adam_steps, mt):
+    g = {}
+    x = seeded.db_like_input(seed + 10, B, T)
+    Tp = T // 4
+    y = seeded.strong_targets(seed + 11, B, Tp)
+    g["meta"] = np.array([B, T, seed], dtype=np.int64)
+    # ---- eval mode (running stats, no dropout)
+    crnn, pred, c1, c2 = build(0.5, seed)
+    g["weight_checksum"] = np.array([c1, c2])
+    crnn.eval(); pred.eval()
+    with torch.no_grad():
+        enc, _ = crnn(t(x))
+        strong, weak = pred(enc)
+    g["eval_enc"], g["eval_strong"], g["eval_weak"] = enc.numpy(), strong.numpy(), weak.numpy()
+    # ---- train mode, dropout = 0 (batch statistics), syn-only loss + Adam
+    crnn, pred, _, _ = build(0.0, seed)
+    crnn.train(); pred.train()
+    params = list(crnn.parameters()) + list(pred.parameters())
+    opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999))
+    bce = torch.nn.BCELoss()
+    losses = []
+    for step in range(adam_steps):
+        opt.zero_grad()
+        enc, _ = crnn(t(x))
+        strong, weak = pred(enc)
+        loss = bce(strong, t(y)) + bce(weak, t(y).max(-2)[0])
+        loss.backward()
+        if step == 0:
+            g["train_enc"], g["train_strong"], g["train_weak"] = (
+                enc.detach().numpy(), strong.detach().numpy(), weak.detach().numpy())
+            grads = named_grads([("crnn.", crnn), ("pred.", pred)])
+            g["grad_names"] = np.array(list(grads.keys()))
+            g["grad_norms"] = np.array([np.sqrt((v.astype(np.float64) ** 2).sum()) for v in grads.values()])
+            for k, v in small_tensors(grads).items():
+                g["grad/" + k] = v
+        opt.step()
+        losses.append(float(loss))
+        if step in (0, adam_steps - 1):
+            sd = {"crnn." + k: v.numpy() for k, v in crnn.state_dict().items()}
+            sd.update({"pred." + k: v.numpy() for k, v in pred.state_dict().items()})
+            g[f"adam{step+1}_names"] = np.array(list(sd.keys()))
+            g[f"adam{step+1}_norms"] = np.array([np.sqrt((v.astype(np.float64) ** 2).sum()) for v in sd.values()])
+            for k, v in small_tensors(sd, 512).items():
+                g[f"adam{step+1}/" + k] = v
+    g["train_losses"] = np.array(losses)
+    if mt:
+        # ---- mean-teacher iteration: student(real) vs EMA(noisy real), src/main_baseline.py:337-368,431-498
+        crnn, pred, _, _ = build(0.0, seed)
+        ema_c, ema_p, _, _ = build(0.0, seed + 5)
+        for m in (crnn, pred, ema_c, ema_p):
+            m.train()
+        for p in list(ema_c.parameters()) + list(ema_p.parameters()):
+            p.detach_()
+        xr = seeded.db_like_input(seed + 20, B, T)
+        xe = xr + np.random.default_rng(seed + 21).normal(0, 1.0, xr.shape).astype(np.float32)
+        yw = (np.random.default_rng(seed + 22).random((B, 20)) < 0.2).astype(np.float32)
+        mse = torch.nn.MSELoss()
+        opt = torch.optim.Adam(list(crnn.parameters()) + list(pred.parameters()), lr=1e-3, betas=(0.9, 0.999))
+        opt.zero_grad()
+        enc_s, _ = crnn(t(x)); ss, ws = pred(enc_s)
+        enc_r, _ = crnn(t(xr)); sr_, wr = pred(enc_r)
+        enc_e, _ = ema_c(t(xe)); se, we = ema_p(enc_e)
+        se, we = se.detach(), we.detach()
+        w = 0.7
+        loss = (bce(ss, t(y)) + bce(ws, t(y).max(-2)[0]) + bce(wr, t(yw))
+                + w * mse(sr_, se) + w * mse(wr, we))
+        loss.backward()
+        opt.step()
+        g["mt_loss"] = np.array(float(loss))
+        g["mt_strong_ema"], g["mt_weak_ema"] = se.numpy(), we.numpy()
+        g["mt_strong_real"], g["mt_weak_real"] = sr_.detach().numpy(), wr.detach().numpy()
+        grads = named_grads([("crnn.", crnn), ("pred.", pred)])
+        g["mt_grad_norms"] = np.array([np.sqrt((v.astype(np.float64) ** 2).sum()) for v in grads.values()])
+        for gs in (1, 5000):
+            # The reference call update_ema_variables(crnn, ema_crnn, ...) RAISES for a plain CRNN:
+            # CNN.state_dict() drops a "cnn." level that load_state_dict() then misses.
+            # Its arithmetic is pinned by running it on the consistent sub-modules instead.
+            update_ema_variables(crnn.cnn.cnn, ema_c.cnn.cnn, 0.999, gs)
+            update_ema_variables(crnn.rnn, ema_c.rnn, 0.999, gs)
+            update_ema_variables(pred, ema_p, 0.999, gs)
+            sd = {"crnn." + k: v.numpy().copy() for k, v in ema_c.state_dict().items()}
+            sd.update({"pred." + k: v.numpy().copy() for k, v in ema_p.state_dict().items()})
+            g[f"ema{gs}_names"] = np.array(list(sd.keys()))
+            g[f"ema{gs}_norms"] = np.array([np.sqrt((v.astype(np.float64) ** 2).sum()) for v in sd.values()])
+            for k, v in small_tensors(sd, 512).items():
+                g[f"ema{gs}/" + k] = v
+    np.savez_compressed(os.path.join(OUT, f"crnn_{tag}.npz"), **g)
+    print("wrote crnn_%s.npz" % tag, {k: getattr(v, "shape", None) for k, v in list(g.items())[:6]})
+
+
+def clipd_case():
+    seed = 77
+    B, T = 2, 313
+    rng = np.random.default_rng(seed)
+    f_s = rng.standard_normal((B, T, 256)).astype(np.float32)
+    f_t = rng.standard_normal((B, T, 256)).astype(np.float32)
+    g_s = rng.random((B, T, 20)).astype(np.float32)
+    g_t = rng.random((B, T, 20)).astype(np.float32)
+    disc = Clip_Discriminator(input_dim=8192, dropout=0.5)
+    vals = seeded.load_seeded(disc, seed + 1)
+    disc.train()
+    cdan = ConditionalDomainAdversarialLoss(disc, entropy_conditioning=False, num_classes=20,
+                                            features_dim=256, randomized=False)
+    g = {"meta": np.array([B, T, seed]), "weight_checksum": np.array(seeded.checksum(vals))}
+    for it in range(3):
+        fs, ft = t(f_s).requires_grad_(), t(f_t).requires_grad_()
+        disc.zero_grad()
+        loss = cdan(t(g_s), fs, t(g_t), ft)
+        loss.backward()
+        g[f"loss{it}"] = np.array(float(loss))
+        g[f"dfs_norm{it}"] = np.array(float(fs.grad.norm()))
+        g[f"dft_norm{it}"] = np.array(float(ft.grad.norm()))
+        g[f"dfs{it}"] = fs.grad.numpy()[:, ::16, ::8].copy()
+        gr = named_grads([("", disc)])
+        g[f"dnames"] = np.array(list(gr.keys()))
+        g[f"dgrad_norms{it}"] = np.array([np.sqrt((v.astype(np.float64) ** 2).sum()) for v in gr.values()])
+    with torch.no_grad():
+        disc.eval()
+        g["eval_out"] = disc(t(np.concatenate([f_s, f_t]))).numpy()
+    np.savez_compressed(os.path.join(OUT, "clipd.npz"), **g)
+    print("wrote clipd.npz")
+
+
+def init_case():
+    torch.manual_seed(2023)
+    crnn, pred = CRNN(**CRNN_KWARGS), Predictor(**PREDICTOR_KWARGS)
+    crnn.apply(weights_init)
+    pred.apply(weights_init)
+    stats = {}
+    for pfx, m in (("crnn.", crnn), ("pred.", pred)):
+        for k, v in m.state_dict().items():
+            v = v.double()
+            stats[pfx + k] = [float(v.mean()), float(v.std()) if v.numel() > 1 else 0.0,
+                              float(v.abs().max()), float(v.abs().sum())]
+    w = crnn.state_dict()["rnn.rnn.weight_hh_l0"].double()
+    stats["_gru_hh_gram_err"] = float((w.T @ w - torch.eye(128, dtype=torch.double)).abs().max())
+    json.dump(stats, open(os.path.join(OUT, "weights_init.json"), "w"), indent=0)
+    print("wrote weights_init.json")
+
+
+def schedule_case():
+    out = {"sigmoid_rampdown_30": [ramps.sigmoid_rampdown(e, 30) for e in range(0, 40, 3)],
+           "exp_rampup_50": [ramps.exp_rampup(e, 50) for e in range(0, 60, 5)]}
+
+    class _Opt:
+        def __init__(self):
+            self.param_groups = [{"lr": 0.0}]
+    lrs = []
+    for e in (0, 10, 29, 30, 99, 100, 101, 120, 121, 141, 299):
+        o, od, oc = _Opt(), _Opt(), _Opt()
+        adjust_learning_rate(o, ramps.sigmoid_rampdown(e, 30), optimizer_d=od, optimizer_crnn=oc, c_epoch=e)
+        lrs.append([e, o.param_groups[0]["lr"], od.param_groups[0]["lr"], oc.param_groups[0]["lr"]])
+    out["adjust_learning_rate"] = lrs
+    from DA.grl import WarmStartGradientReverseLayer
+    grl = WarmStartGradientReverseLayer(alpha=1., lo=0., hi=1., max_iters=1000, auto_step=True)
+    coeffs = []
+    for it in range(5):
+        x = torch.ones(1, requires_grad=True)
+        grl(x).sum().backward()
+        coeffs.append(float(-x.grad))
+    out["grl_coeff_first5"] = coeffs
+    json.dump(out, open(os.path.join(OUT, "schedules.json"), "w"), indent=0)
+    print("wrote schedules.json")
+
+
+def labels_case():
+    import pandas as pd
+    df = pd.read_csv("/root/reference/dataset/SYN/generated/output.tsv", sep="\t")
+    enc = ManyHotEncoder(BIRD_LIST, n_frames=313)
+    cases = []
+    for fname in list(dict.fromkeys(df.filename))[:12]:
+        sub = df[df.filename == fname]
+        y = enc.encode_strong_df(sub)
+        rows = [[float(r.onset), float(r.offset), r.event_label] for r in sub.itertuples()]
+        nz = np.argwhere(y > 0)
+        cases.append({"filename": fname, "events": rows, "sum": float(y.sum()),
+                      "first_last": {c: [int(nz[nz[:, 1] == BIRD_LIST.index(c), 0].min()),
+                                         int(nz[nz[:, 1] == BIRD_LIST.index(c), 0].max()) + 1]
+                                     for c in sorted(set(sub.event_label))
+                                     if (nz[:, 1] == BIRD_LIST.index(c)).any()},
+                      "weak": enc.encode_weak(list(sub.event_label)).tolist(),
+                      "col_sums": y.sum(0).tolist()})
+    json.dump(cases, open(os.path.join(OUT, "labels_kat.json"), "w"), indent=0)
+    print("wrote labels_kat.json")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    labels_case()
+    schedule_case()
+    init_case()
+    clipd_case()
+    crnn_case("small", B=2, T=64, seed=11, adam_steps=3, mt=True)
+    crnn_case("R", B=2, T=1255, seed=23, adam_steps=1, mt=False)
