@@ -138,9 +138,10 @@ def test_weights_init_statistics(golden_dir):
     for pfx, m in (("crnn.", crnn), ("pred.", pred)):
         for k, v in m.state_dict().items():
             stats[pfx + k] = v.double()
-    for k, (mean, std, amax, asum) in ref.items():
+    for k, val in ref.items():
         if k.startswith("_"):
             continue
+        mean, std, amax, asum = val
         v = stats[k]
         # same seed + same traversal order => same draws (LAPACK-dependent last bits for orthogonal_)
         assert abs(float(v.mean()) - mean) < 1e-5 + 1e-4 * abs(mean), k
@@ -174,14 +175,14 @@ def test_label_frame_indexing(golden_dir):
 
 
 def test_decode_and_post_process_roundtrip():
-    y = lo.encode_strong([(1.0, 3.0, "EATO"), (5.0, 5.3, "AMCR"), (2.0, 9.99, "BAWW")], 313)
+    y = lo.encode_strong([(1.0, 3.0, "EATO"), (5.0, 5.15, "AMCR"), (2.0, 9.99, "BAWW")], 313)
     ev = lo.decode_strong(y)
     assert sorted(ev) == sorted([["EATO", lo.frame_index(1.0), lo.frame_index(3.0)],
-                                 ["AMCR", lo.frame_index(5.0), lo.frame_index(5.3)],
+                                 ["AMCR", lo.frame_index(5.0), lo.frame_index(5.15)],
                                  ["BAWW", lo.frame_index(2.0), lo.frame_index(9.99)]])
     post = lo.post_process(y * 0.9, median_window=14)
     labs = [p[0] for p in post]
-    assert "EATO" in labs and "BAWW" in labs and "AMCR" not in labs  # 9-frame event < median 14
+    assert "EATO" in labs and "BAWW" in labs and "AMCR" not in labs  # 4-frame event loses the 14-frame median vote
     for _, on, off in post:
         assert 0.0 <= on < off <= 10.0
 
@@ -209,7 +210,7 @@ def test_mel_sinusoid_silence_and_clamp():
     mel = mo.preprocess(np.zeros(n, dtype=np.float32))
     assert mel.shape == (126, 128) and mel.dtype == np.float32
     db = mo.amplitude_to_db(mel.T).T
-    assert np.all(db == -100.0)
+    assert np.all(np.abs(db + 100.0) < 1e-4)  # float32(1e-10) is not exactly 1e-10
     y2, _ = mo.synth_clip(0, seconds=1.0)
     db2 = mo.amplitude_to_db(mo.preprocess(y2).T).T
     assert db2.min() >= db2.max() - 80.0 - 1e-4
