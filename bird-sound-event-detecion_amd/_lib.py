@@ -1,0 +1,91 @@
+"""ctypes binding of libbsed.so (C ABI declared in include/bsed.h).
+
+The library is built in-tree by ``csrc/build.sh`` (``__graft_entry__.build()``) and is the ONLY
+compute path: ``lib()`` raises if it is missing -- there is no eager/PyTorch fallback.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbsed.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bsed.h")
+
+_lib = None
+
+
+class BsedError(RuntimeError):
+    pass
+
+
+class MelCfg(ctypes.Structure):
+    _fields_ = [("sr", ctypes.c_int), ("n_fft", ctypes.c_int), ("hop", ctypes.c_int),
+                ("n_mels", ctypes.c_int), ("fmin", ctypes.c_float), ("fmax", ctypes.c_float)]
+
+
+def header_symbols():
+    """Every function name declared in include/bsed.h."""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(bsed_[a-z0-9_]+)\s*\(", txt)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BsedError(f"{LIB_PATH} is missing: build it with csrc/build.sh "
+                            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        L.bsed_last_error.restype = ctypes.c_char_p
+        L.bsed_build_info.restype = ctypes.c_char_p
+        for name in header_symbols():
+            fn = getattr(L, name)  # AttributeError = header/library mismatch: fail loudly
+            if name not in ("bsed_last_error", "bsed_build_info"):
+                fn.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise BsedError(f"{what} failed ({rc}): {lib().bsed_last_error().decode()}")
+
+
+def _require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise BsedError("bsed_amd needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+
+
+def ptr(t, dtype=None):
+    """Device pointer of a contiguous CUDA(HIP) tensor, or NULL for None."""
+    import torch
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise BsedError("expected a GPU tensor")
+    if not t.is_contiguous():
+        raise BsedError("expected a contiguous tensor")
+    want = torch.float32 if dtype is None else dtype
+    if t.dtype != want:
+        raise BsedError(f"expected dtype {want}, got {t.dtype}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    """Call an int-returning entry point; ints/floats are passed with explicit ctypes."""
+    fn = getattr(lib(), name)
+    check(fn(*args), name)
+
+
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_u64 = ctypes.c_uint64
+c_void_p = ctypes.c_void_p
+c_size_t = ctypes.c_size_t

@@ -1,0 +1,89 @@
+// Shared device/host helpers for the bsed HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define BSED_OK 0
+#define BSED_ERR_ARG (-1)
+#define BSED_ERR_HIP (-2)
+#define BSED_ERR_STATE (-3)
+
+void bsed_set_error(const char* fmt, ...);
+
+#define BSED_CHECK_ARG(cond, ...)                 \
+  do {                                            \
+    if (!(cond)) {                                \
+      bsed_set_error(__VA_ARGS__);                \
+      return BSED_ERR_ARG;                        \
+    }                                             \
+  } while (0)
+
+#define BSED_LAUNCH_CHECK()                                                         \
+  do {                                                                              \
+    hipError_t e__ = hipGetLastError();                                             \
+    if (e__ != hipSuccess) {                                                        \
+      bsed_set_error("%s:%d HIP launch error: %s", __FILE__, __LINE__,              \
+                     hipGetErrorString(e__));                                       \
+      return BSED_ERR_HIP;                                                          \
+    }                                                                               \
+  } while (0)
+
+#define BSED_HIP(call)                                                              \
+  do {                                                                              \
+    hipError_t e__ = (call);                                                        \
+    if (e__ != hipSuccess) {                                                        \
+      bsed_set_error("%s:%d %s: %s", __FILE__, __LINE__, #call,                     \
+                     hipGetErrorString(e__));                                       \
+      return BSED_ERR_HIP;                                                          \
+    }                                                                               \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+#if defined(__HIPCC__)
+// ----------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG: stateless, keyed on (seed, stream) with a 64-bit element counter, so
+// forward and backward regenerate identical dropout masks without storing them.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32(uint64_t counter, uint32_t stream, uint64_t seed) {
+  uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = stream, c3 = 0x5eed5eedu;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}
+
+// keep-mask for one element: element index e -> 32-bit word (e & 3) of philox(e >> 2)
+__device__ __forceinline__ float dropout_scale(uint64_t e, uint32_t stream, uint64_t seed, float p) {
+  if (p <= 0.f) return 1.f;
+  uint4 r = philox4x32(e >> 2, stream, seed);
+  uint32_t w = (e & 3) == 0 ? r.x : (e & 3) == 1 ? r.y : (e & 3) == 2 ? r.z : r.w;
+  // uniform in [0,1): keep if u >= p
+  float u = (float)(w >> 8) * (1.0f / 16777216.0f);
+  return u >= p ? 1.0f / (1.0f - p) : 0.f;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+#endif

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libbsed.so for gfx950 in-tree (the .so travels to the GPU box with the snapshot).
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+mkdir -p obj
+pids=()
+for f in *.hip; do
+  o=obj/${f%.hip}.o
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ bsed_common.h -nt "$o" ] || [ ../../include/bsed.h -nt "$o" ] \
+     || { [ -f igemm_core.h ] && [ igemm_core.h -nt "$o" ]; }; then
+    $HIPCC $FLAGS -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libbsed.so obj/*.o
+echo "built $(realpath ../libbsed.so)"
