@@ -1,0 +1,408 @@
+// CNN pieces that are HBM-bound streaming passes rather than contractions.
+//
+//   conv0_fwd_kernel     first conv (Cin = 1): a 9-tap stencil, no MFMA          [src/models/CNN.py:46-47, i = 0]
+//   conv0_wgrad_kernel   its weight gradient (thread-private 9 x CO accumulators)
+//   stats_reduce_kernel  per-tile (sum, sumsq) partials -> fp64 per-channel sums
+//   bn_finalize_kernel   BatchNorm2d(eps, momentum) train-mode statistics -> scale/shift + running stats
+//                                                                               [src/models/CNN.py:49]
+//   bn_eval_kernel       eval-mode scale/shift from the running statistics
+//   bn_bwd_finalize / bn_bwd_apply   BatchNorm backward as one affine map d_y = A g + B (y-mean) + C
+//   colsum / bias helpers
+#include "bsed_common.h"
+#include "../../include/bsed.h"
+#include <algorithm>
+
+// ---------------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        float* __restrict__ stats, int H, int W, long per_img) {
+  __shared__ float ws[CO * 9 + CO];
+  __shared__ float sv[256 * (CO + 1)];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < CO * 9 + CO; i += 256) ws[i] = i < CO * 9 ? w[i] : bias[i - CO * 9];
+  __syncthreads();
+  const int nb = blockIdx.y;
+  const long pos = (long)blockIdx.x * 256 + tid;
+  const bool ok = pos < per_img;
+  float out[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) out[c] = 0.f;
+  if (ok) {
+    const int h = (int)(pos / W), wq = (int)(pos % W);
+    const float* xi = x + (size_t)nb * per_img;
+    float in9[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int hh = h + kh - 1, ww = wq + kw - 1;
+        in9[kh * 3 + kw] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xi[(size_t)hh * W + ww] : 0.f;
+      }
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      float a = ws[CO * 9 + c];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) a = fmaf(in9[t], ws[c * 9 + t], a);
+      out[c] = a;
+    }
+    float4* dst = reinterpret_cast<float4*>(y + ((size_t)nb * per_img + pos) * CO);
+#pragma unroll
+    for (int c = 0; c < CO; c += 4) dst[c / 4] = make_float4(out[c], out[c + 1], out[c + 2], out[c + 3]);
+  }
+  if (stats) {
+#pragma unroll
+    for (int c = 0; c < CO; ++c) sv[tid * (CO + 1) + c] = out[c];  // zeros for out-of-range positions
+    __syncthreads();
+    // thread (c, g): channel c over positions g*PG .. g*PG+PG-1
+    constexpr int NG = 256 / CO;   // groups
+    constexpr int PG = 256 / NG;   // positions per group (= CO)
+    {
+      const int c = tid % CO, g = tid / CO;
+      float s = 0.f, q = 0.f;
+      for (int i = 0; i < PG; ++i) {
+        const float v = sv[(g * PG + i) * (CO + 1) + c];
+        s += v;
+        q = fmaf(v, v, q);
+      }
+      __syncthreads();
+      sv[tid] = s;
+      sv[256 + tid] = q;
+    }
+    __syncthreads();
+    if (tid < 2 * CO) {
+      const int which = tid / CO, c = tid % CO;
+      float s = 0.f;
+      for (int g = 0; g < NG; ++g) s += sv[which * 256 + g * CO + c];
+      const long blk = (long)nb * gridDim.x + blockIdx.x;
+      stats[(blk * 2 + which) * CO + c] = s;
+    }
+  }
+}
+
+// dW0[co][tap] partials: part[blk][tap][co]
+template <int CO>
+__global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ part, int NB, int H, int W) {
+  __shared__ float sv[256 * (CO + 1)];
+  const int tid = threadIdx.x;
+  const long per_img = (long)H * W, total = per_img * NB;
+  float acc[9][CO];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[t][c] = 0.f;
+  for (long p = (long)blockIdx.x * 256 + tid; p < total; p += (long)gridDim.x * 256) {
+    const long nb = p / per_img, q = p - nb * per_img;
+    const int h = (int)(q / W), wq = (int)(q % W);
+    const float* xi = x + nb * per_img;
+    float g[CO];
+    const float4* src = reinterpret_cast<const float4*>(dy + (size_t)p * CO);
+#pragma unroll
+    for (int c = 0; c < CO; c += 4) {
+      const float4 v = src[c / 4];
+      g[c] = v.x; g[c + 1] = v.y; g[c + 2] = v.z; g[c + 3] = v.w;
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int hh = h + kh - 1, ww = wq + kw - 1;
+        const float xv = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xi[(size_t)hh * W + ww] : 0.f;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[kh * 3 + kw][c] = fmaf(xv, g[c], acc[kh * 3 + kw][c]);
+      }
+  }
+  constexpr int NG = 256 / CO, PG = CO;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CO; ++c) sv[tid * (CO + 1) + c] = acc[t][c];
+    __syncthreads();
+    const int c = tid % CO, g = tid / CO;
+    float s = 0.f;
+    for (int i = 0; i < PG; ++i) s += sv[(g * PG + i) * (CO + 1) + c];
+    __syncthreads();
+    sv[tid] = s;
+    __syncthreads();
+    if (tid < CO) {
+      float r = 0.f;
+      for (int gg = 0; gg < NG; ++gg) r += sv[gg * CO + tid];
+      part[((size_t)blockIdx.x * 9 + t) * CO + tid] = r;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// partial[tile][2][C] (fp32) -> sums[chunk][2][C] (fp64); a second call with ntiles = nchunks and
+// in_double = 1 finishes the reduction.
+__global__ __launch_bounds__(256) void stats_reduce_kernel(const void* __restrict__ partial, int in_double,
+                                                           long ntiles, int C, double* __restrict__ out) {
+  __shared__ double sm[256];
+  const int tid = threadIdx.x;
+  const int cl = tid & 31, g = tid >> 5;  // 32 channels x 8 tile groups
+  const int c = blockIdx.y * 32 + cl;
+  const long chunk = blockIdx.x, nchunks = gridDim.x;
+  const long per = (ntiles + nchunks - 1) / nchunks;
+  const long t0 = chunk * per, t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
+  for (int which = 0; which < 2; ++which) {
+    double s = 0.0;
+    if (c < C) {
+      if (in_double) {
+        const double* p = reinterpret_cast<const double*>(partial);
+        for (long t = t0 + g; t < t1; t += 8) s += p[(t * 2 + which) * C + c];
+      } else {
+        const float* p = reinterpret_cast<const float*>(partial);
+        for (long t = t0 + g; t < t1; t += 8) s += (double)p[(t * 2 + which) * C + c];
+      }
+    }
+    __syncthreads();
+    sm[tid] = s;
+    __syncthreads();
+    if (g == 0 && c < C) {
+      double r = 0.0;
+      for (int gg = 0; gg < 8; ++gg) r += sm[gg * 32 + cl];
+      out[(chunk * 2 + which) * C + c] = r;
+    }
+  }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, double count, float eps, float momentum,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   long long* __restrict__ num_batches_tracked, float* __restrict__ mean_out,
+                                   float* __restrict__ invstd_out, float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  if (c >= C) return;
+  const double mean = sums[c] / count;
+  double var = sums[C + c] / count - mean * mean;
+  if (var < 0) var = 0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  mean_out[c] = (float)mean;
+  invstd_out[c] = (float)invstd;
+  const float sc = gamma[c] * (float)invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  if (running_mean) {
+    const double unbiased = count > 1 ? var * count / (count - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_kernel(int C, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                               float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(running_var[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - running_mean[c] * sc;
+}
+
+// sums = (sum g, sum g*y) -> dgamma, dbeta and the coefficients of d_y = A g + B (y - mean) + Cc
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int C, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double sg = sums[c], sgy = sums[C + c];
+  const double m = mean[c], is = invstd[c];
+  const double dgam = (sgy - m * sg) * is;
+  const double A = (double)gamma[c] * is;
+  coef[c] = (float)A;
+  coef[C + c] = (float)(-A * is * dgam / count);
+  coef[2 * C + c] = (float)(-A * sg / count);
+  if (accumulate) {
+    dgamma[c] += (float)dgam;
+    dbeta[c] += (float)sg;
+  } else {
+    dgamma[c] = (float)dgam;
+    dbeta[c] = (float)sg;
+  }
+}
+
+__global__ void bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ coef,
+                                    const float* __restrict__ mean, long n4, int C) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % C);
+    float4 gv = reinterpret_cast<float4*>(g)[i];
+    const float4 yv = reinterpret_cast<const float4*>(y)[i];
+    const float4 A = *reinterpret_cast<const float4*>(coef + c);
+    const float4 B = *reinterpret_cast<const float4*>(coef + C + c);
+    const float4 Cc = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+    const float4 m = *reinterpret_cast<const float4*>(mean + c);
+    gv.x = fmaf(A.x, gv.x, fmaf(B.x, yv.x - m.x, Cc.x));
+    gv.y = fmaf(A.y, gv.y, fmaf(B.y, yv.y - m.y, Cc.y));
+    gv.z = fmaf(A.z, gv.z, fmaf(B.z, yv.z - m.z, Cc.z));
+    gv.w = fmaf(A.w, gv.w, fmaf(B.w, yv.w - m.w, Cc.w));
+    reinterpret_cast<float4*>(g)[i] = gv;
+  }
+}
+
+// dst[c] (+)= sums[which][c]
+__global__ void sums_to_grad_kernel(const double* __restrict__ sums, int C, int which, float* __restrict__ dst,
+                                    int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float v = (float)sums[which * C + c];
+  dst[c] = accumulate ? dst[c] + v : v;
+}
+
+// per-block column sums of a (M, C) matrix with row pitch: part[blk][2][C] (slot 1 = 0), fed to stats_reduce
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, long M, int C, int pitch,
+                                                     float* __restrict__ part) {
+  __shared__ float sm[256];
+  const int tid = threadIdx.x, cl = tid & 31, g = tid >> 5;
+  const long per = (M + gridDim.x - 1) / gridDim.x;
+  const long r0 = (long)blockIdx.x * per, r1 = (r0 + per < M) ? r0 + per : M;
+  for (int cb = 0; cb < C; cb += 32) {
+    const int c = cb + cl;
+    float s = 0.f;
+    if (c < C)
+      for (long r = r0 + g; r < r1; r += 8) s += in[r * pitch + c];
+    __syncthreads();
+    sm[tid] = s;
+    __syncthreads();
+    if (g == 0 && c < C) {
+      float t = 0.f;
+      for (int gg = 0; gg < 8; ++gg) t += sm[gg * 32 + cl];
+      part[((size_t)blockIdx.x * 2 + 0) * C + c] = t;
+      part[((size_t)blockIdx.x * 2 + 1) * C + c] = 0.f;
+    }
+  }
+}
+
+// elementwise dropout: out = in * keep/(1-p)   (forward and backward use the same call)
+__global__ void dropout_kernel(const float* __restrict__ in, float* __restrict__ out, long n, float p,
+                               uint32_t rng_stream, uint64_t seed) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = in[i] * dropout_scale((uint64_t)i, rng_stream, seed, p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" int bsed_conv0_fwd(const float* x, const float* w, const float* bias, float* y, float* stats, int NB, int H,
+                              int W, int CO, void* stream) {
+  BSED_CHECK_ARG(x && w && bias && y, "bsed_conv0_fwd: null tensor");
+  BSED_CHECK_ARG(NB > 0 && NB <= 65535 && H > 0 && W > 0, "bsed_conv0_fwd: bad shape");
+  const long per = (long)H * W;
+  dim3 grid(ceil_div(per, 256), NB);
+  hipStream_t s = (hipStream_t)stream;
+  if (CO == 16) hipLaunchKernelGGL(conv0_fwd_kernel<16>, grid, dim3(256), 0, s, x, w, bias, y, stats, H, W, per);
+  else if (CO == 32) hipLaunchKernelGGL(conv0_fwd_kernel<32>, grid, dim3(256), 0, s, x, w, bias, y, stats, H, W, per);
+  else { bsed_set_error("bsed_conv0_fwd: first-layer width %d not built (16 or 32)", CO); return BSED_ERR_ARG; }
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_conv0_num_tiles(int NB, int H, int W) { return NB * ceil_div((long)H * W, 256); }
+
+extern "C" int bsed_conv0_wgrad(const float* x, const float* dy, float* part, int G, int NB, int H, int W, int CO,
+                                void* stream) {
+  BSED_CHECK_ARG(x && dy && part && G > 0 && NB > 0 && H > 0 && W > 0, "bsed_conv0_wgrad: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (CO == 16) hipLaunchKernelGGL(conv0_wgrad_kernel<16>, dim3(G), dim3(256), 0, s, x, dy, part, NB, H, W);
+  else if (CO == 32) hipLaunchKernelGGL(conv0_wgrad_kernel<32>, dim3(G), dim3(256), 0, s, x, dy, part, NB, H, W);
+  else { bsed_set_error("bsed_conv0_wgrad: first-layer width %d not built (16 or 32)", CO); return BSED_ERR_ARG; }
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+#define STATS_CHUNKS 128
+
+extern "C" size_t bsed_stats_scratch_bytes(int C) { return (size_t)(STATS_CHUNKS + 1) * 2 * C * sizeof(double); }
+
+// partial (ntiles,2,C) fp32 -> sums (2,C) fp64 at scratch + STATS_CHUNKS*2*C
+static int stats_reduce(const float* partial, long ntiles, int C, double* scratch, hipStream_t s) {
+  const int chunks = (int)std::min<long>(STATS_CHUNKS, ntiles);
+  dim3 g1(chunks, ceil_div(C, 32));
+  hipLaunchKernelGGL(stats_reduce_kernel, g1, dim3(256), 0, s, (const void*)partial, 0, ntiles, C, scratch);
+  dim3 g2(1, ceil_div(C, 32));
+  hipLaunchKernelGGL(stats_reduce_kernel, g2, dim3(256), 0, s, (const void*)scratch, 1, (long)chunks, C,
+                     scratch + (size_t)STATS_CHUNKS * 2 * C);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_bn_finalize(const float* partial, long ntiles, int C, double count, float eps, float momentum,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                long long* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                                void* scratch, void* stream) {
+  BSED_CHECK_ARG(partial && gamma && beta && mean && invstd && scale && shift && scratch, "bsed_bn_finalize: null tensor");
+  BSED_CHECK_ARG(ntiles > 0 && C > 0 && count > 0, "bsed_bn_finalize: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  double* sc = (double*)scratch;
+  int rc = stats_reduce(partial, ntiles, C, sc, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, sc + (size_t)STATS_CHUNKS * 2 * C, C,
+                     count, eps, momentum, gamma, beta, running_mean, running_var, num_batches_tracked, mean, invstd,
+                     scale, shift);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_bn_eval(int C, float eps, const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float* scale, float* shift, void* stream) {
+  BSED_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && C > 0, "bsed_bn_eval: bad argument");
+  hipLaunchKernelGGL(bn_eval_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, (hipStream_t)stream, C, eps, gamma, beta,
+                     running_mean, running_var, scale, shift);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_bn_bwd(const float* partial, long ntiles, int C, double count, const float* gamma,
+                           const float* mean, const float* invstd, float* dgamma, float* dbeta, int accumulate,
+                           float* g_inout, const float* y, long n_elems, float* coef, void* scratch, void* stream) {
+  BSED_CHECK_ARG(partial && gamma && mean && invstd && dgamma && dbeta && g_inout && y && coef && scratch,
+                 "bsed_bn_bwd: null tensor");
+  BSED_CHECK_ARG(ntiles > 0 && C > 0 && C % 4 == 0 && n_elems % C == 0, "bsed_bn_bwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  double* sc = (double*)scratch;
+  int rc = stats_reduce(partial, ntiles, C, sc, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s,
+                     sc + (size_t)STATS_CHUNKS * 2 * C, C, count, gamma, mean, invstd, dgamma, dbeta, accumulate, coef);
+  const long n4 = n_elems / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)std::min<long>(ceil_div(n4, 256), 8192)), dim3(256), 0, s,
+                     g_inout, y, coef, mean, n4, C);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+// dst[c] (+)= sum over tiles of partial[tile][which][c]
+extern "C" int bsed_stats_to_grad(const float* partial, long ntiles, int C, int which, float* dst, int accumulate,
+                                  void* scratch, void* stream) {
+  BSED_CHECK_ARG(partial && dst && scratch && ntiles > 0 && C > 0 && (which == 0 || which == 1), "bsed_stats_to_grad: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  double* sc = (double*)scratch;
+  int rc = stats_reduce(partial, ntiles, C, sc, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(sums_to_grad_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, sc + (size_t)STATS_CHUNKS * 2 * C, C,
+                     which, dst, accumulate);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+// dst[c] (+)= sum_r in[r][c]; part must hold G*2*C floats
+extern "C" int bsed_colsum(const float* in, long M, int C, int pitch, float* part, int G, float* dst, int accumulate,
+                           void* scratch, void* stream) {
+  BSED_CHECK_ARG(in && part && dst && scratch && M > 0 && C > 0 && pitch >= C && G > 0, "bsed_colsum: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int g = (int)std::min<long>(G, M);
+  hipLaunchKernelGGL(colsum_kernel, dim3(g), dim3(256), 0, s, in, M, C, pitch, part);
+  return bsed_stats_to_grad(part, g, C, 0, dst, accumulate, scratch, stream);
+}
+
+extern "C" int bsed_dropout(const float* in, float* out, long n, float p, uint32_t rng_stream, uint64_t seed,
+                            void* stream) {
+  BSED_CHECK_ARG(in && out && n > 0 && p >= 0.f && p < 1.f, "bsed_dropout: bad argument");
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)std::min<long>(ceil_div(n, 256), 8192)), dim3(256), 0,
+                     (hipStream_t)stream, in, out, n, p, rng_stream, seed);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}

@@ -1,0 +1,258 @@
+// Predictor head + training losses, one workgroup per clip.
+//
+//   head_fwd_kernel : strong = sigmoid(x Wd^T + bd); p = softmax_class(x Ws^T + bs);
+//                     a = clamp(p, 1e-7, 1); weak = sum_t strong*a / sum_t a
+//                     [reference src/models/CRNN_GRL.py:441-460, Predictor.forward]
+//   head_bwd_kernel : BCE(strong, y) + BCE(weak, y_weak) + w*(MSE(strong, strong_ema) + MSE(weak, weak_ema))
+//                     and their gradients back to x, Wd, bd, Ws, bs in one pass
+//                     [reference src/main_baseline.py:431-498: nn.BCELoss (log clamped at -100, gradient
+//                      (s-y)/max(s(1-s),1e-12)), nn.MSELoss, all reduction='mean']
+#include "bsed_common.h"
+#include "../../include/bsed.h"
+
+#define HD_K 256       // 2 * n_RNN_cell
+#define HD_MAXC 20     // classes per head handled by one thread group
+#define HD_FR 32       // frames per chunk
+#define HD_THREADS 256
+
+// logits for a chunk of frames: lg[f][0..C) dense head, lg[f][C..2C) softmax head
+template <int C>
+__device__ __forceinline__ void head_logits(const float* xs /*[HD_FR][HD_K+1]*/, const float* ws /*[2C][HD_K+1]*/,
+                                            const float* bs /*[2C]*/, float* lg /*[HD_FR][2C]*/, int tid) {
+  constexpr int PER = (2 * C) / 8;  // outputs per thread (8 threads per frame)
+  const int f = tid >> 3, cg = tid & 7;
+  float acc[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) acc[i] = bs[cg * PER + i];
+  for (int k = 0; k < HD_K; ++k) {
+    const float xv = xs[f * (HD_K + 1) + k];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) acc[i] = fmaf(xv, ws[(cg * PER + i) * (HD_K + 1) + k], acc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) lg[f * (2 * C) + cg * PER + i] = acc[i];
+}
+
+template <int C>
+__global__ __launch_bounds__(HD_THREADS) void head_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w /*(2C,256): dense rows then softmax rows*/,
+    const float* __restrict__ b /*(2C)*/, float* __restrict__ strong, float* __restrict__ sof_raw,
+    float* __restrict__ weak, float* __restrict__ den_out, int T, int attention) {
+  extern __shared__ __align__(16) float smem[];
+  float* ws = smem;                          // [2C][257]
+  float* xs = ws + 2 * C * (HD_K + 1);       // [32][257]
+  float* lg = xs + HD_FR * (HD_K + 1);       // [32][2C]
+  float* bsm = lg + HD_FR * 2 * C;           // [2C]
+  float* sS = bsm + 2 * C;                   // [32][C]
+  float* sA = sS + HD_FR * C;                // [32][C]
+  const int tid = threadIdx.x, b_ = blockIdx.x;
+  for (int i = tid; i < 2 * C * HD_K; i += HD_THREADS) ws[(i / HD_K) * (HD_K + 1) + (i % HD_K)] = w[i];
+  if (tid < 2 * C) bsm[tid] = b[tid];
+  float num = 0.f, den = 0.f;
+  for (int f0 = 0; f0 < T; f0 += HD_FR) {
+    __syncthreads();
+    for (int i = tid; i < HD_FR * HD_K; i += HD_THREADS) {
+      const int f = i / HD_K, k = i % HD_K;
+      xs[f * (HD_K + 1) + k] = (f0 + f < T) ? x[((size_t)b_ * T + f0 + f) * HD_K + k] : 0.f;
+    }
+    __syncthreads();
+    head_logits<C>(xs, ws, bsm, lg, tid);
+    __syncthreads();
+    if (tid < HD_FR) {
+      const int f = tid;
+      const bool ok = f0 + f < T;
+      float mx = -3.0e38f;
+      for (int c = 0; c < C; ++c) mx = fmaxf(mx, lg[f * 2 * C + C + c]);
+      float e[C], se = 0.f;
+      for (int c = 0; c < C; ++c) { e[c] = expf(lg[f * 2 * C + C + c] - mx); se += e[c]; }
+      const float inv = 1.0f / se;
+      for (int c = 0; c < C; ++c) {
+        const float s = sigmoidf_(lg[f * 2 * C + c]);
+        const float p = e[c] * inv;
+        const float a = attention ? fminf(fmaxf(p, 1e-7f), 1.0f) : 1.0f;
+        sS[f * C + c] = ok ? s : 0.f;
+        sA[f * C + c] = ok ? a : 0.f;
+        if (ok) {
+          strong[((size_t)b_ * T + f0 + f) * C + c] = s;
+          sof_raw[((size_t)b_ * T + f0 + f) * C + c] = p;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < C) {
+      for (int f = 0; f < HD_FR; ++f) {
+        num = fmaf(sS[f * C + tid], sA[f * C + tid], num);
+        den += sA[f * C + tid];
+      }
+    }
+  }
+  if (tid < C) {
+    weak[(size_t)b_ * C + tid] = num / den;
+    den_out[(size_t)b_ * C + tid] = den;
+  }
+}
+
+// BCE element (PyTorch semantics): value with log clamped at -100
+__device__ __forceinline__ float bce_val(float s, float y) {
+  return -(y * fmaxf(logf(s), -100.f) + (1.f - y) * fmaxf(logf(1.f - s), -100.f));
+}
+__device__ __forceinline__ float bce_grad(float s, float y) { return (s - y) / fmaxf((1.f - s) * s, 1e-12f); }
+
+template <int C>
+__global__ __launch_bounds__(HD_THREADS) void head_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ strong,
+    const float* __restrict__ sof_raw, const float* __restrict__ weak, const float* __restrict__ den,
+    const float* __restrict__ y_strong, const float* __restrict__ y_weak, const float* __restrict__ ema_strong,
+    const float* __restrict__ ema_weak, const float* __restrict__ g_strong_ext, const float* __restrict__ g_weak_ext,
+    float w_strong, float w_weak, float w_cons_s, float w_cons_w, float inv_n_strong, float inv_n_weak,
+    float* __restrict__ dx, float* __restrict__ dw_part /*(B,2C,256)*/, float* __restrict__ db_part /*(B,2C)*/,
+    float* __restrict__ loss_part /*(B,4)*/, int T, int attention) {
+  extern __shared__ __align__(16) float smem[];
+  float* ws = smem;                          // [2C][257]
+  float* xs = ws + 2 * C * (HD_K + 1);       // [32][257]
+  float* dl = xs + HD_FR * (HD_K + 1);       // [32][2C]
+  float* gwk = dl + HD_FR * 2 * C;           // [C] d loss / d weak
+  float* wk = gwk + C;                       // [C]
+  float* dn = wk + C;                        // [C]
+  float* lred = dn + C;                      // [HD_THREADS]
+  const int tid = threadIdx.x, b_ = blockIdx.x;
+  for (int i = tid; i < 2 * C * HD_K; i += HD_THREADS) ws[(i / HD_K) * (HD_K + 1) + (i % HD_K)] = w[i];
+  float l_s = 0.f, l_w = 0.f, l_cs = 0.f, l_cw = 0.f;
+  if (tid < C) {
+    const float wv = weak[(size_t)b_ * C + tid];
+    float g = 0.f;
+    if (y_weak) {
+      const float yv = y_weak[(size_t)b_ * C + tid];
+      g += w_weak * bce_grad(wv, yv) * inv_n_weak;
+      l_w = bce_val(wv, yv);
+    }
+    if (ema_weak) {
+      const float d = wv - ema_weak[(size_t)b_ * C + tid];
+      g += w_cons_w * 2.f * d * inv_n_weak;
+      l_cw = d * d;
+    }
+    if (g_weak_ext) g += g_weak_ext[(size_t)b_ * C + tid];
+    gwk[tid] = g;
+    wk[tid] = wv;
+    dn[tid] = den[(size_t)b_ * C + tid];
+  }
+  float dwacc[2 * C];
+#pragma unroll
+  for (int c = 0; c < 2 * C; ++c) dwacc[c] = 0.f;
+  float dbacc = 0.f;  // thread c < 2C accumulates its bias gradient
+  for (int f0 = 0; f0 < T; f0 += HD_FR) {
+    __syncthreads();
+    for (int i = tid; i < HD_FR * HD_K; i += HD_THREADS) {
+      const int f = i / HD_K, k = i % HD_K;
+      xs[f * (HD_K + 1) + k] = (f0 + f < T) ? x[((size_t)b_ * T + f0 + f) * HD_K + k] : 0.f;
+    }
+    if (tid < HD_FR) {
+      const int f = tid;
+      const bool ok = f0 + f < T;
+      const size_t o = ((size_t)b_ * T + f0 + f) * C;
+      float ga[C], pa[C], dot = 0.f;
+      for (int c = 0; c < C; ++c) {
+        float dls = 0.f;
+        ga[c] = 0.f; pa[c] = 0.f;
+        if (ok) {
+          const float s = strong[o + c];
+          const float p = sof_raw[o + c];
+          const float a = attention ? fminf(fmaxf(p, 1e-7f), 1.0f) : 1.0f;
+          float gs = gwk[c] * a / dn[c];
+          if (y_strong) {
+            const float yv = y_strong[o + c];
+            gs += w_strong * bce_grad(s, yv) * inv_n_strong;
+            l_s += bce_val(s, yv);
+          }
+          if (ema_strong) {
+            const float d = s - ema_strong[o + c];
+            gs += w_cons_s * 2.f * d * inv_n_strong;
+            l_cs += d * d;
+          }
+          if (g_strong_ext) gs += g_strong_ext[o + c];
+          dls = gs * s * (1.f - s);
+          if (attention && p >= 1e-7f && p <= 1.0f) ga[c] = gwk[c] * (s - wk[c]) / dn[c];
+          pa[c] = p;
+          dot = fmaf(ga[c], p, dot);
+        }
+        dl[f * 2 * C + c] = dls;
+      }
+      for (int c = 0; c < C; ++c) dl[f * 2 * C + C + c] = pa[c] * (ga[c] - dot);
+    }
+    __syncthreads();
+    // dx[f][k]: 8 threads per frame, 32 columns each
+    {
+      const int f = tid >> 3, kg = tid & 7;
+      if (f0 + f < T) {
+        float* dxr = dx + ((size_t)b_ * T + f0 + f) * HD_K;
+        for (int kk = 0; kk < 32; ++kk) {
+          const int k = kg + 8 * kk;
+          float a = 0.f;
+#pragma unroll
+          for (int c = 0; c < 2 * C; ++c) a = fmaf(dl[f * 2 * C + c], ws[c * (HD_K + 1) + k], a);
+          dxr[k] = a;
+        }
+      }
+    }
+    // dW[c][k = tid] += sum_f dl[f][c] * x[f][k]
+    for (int f = 0; f < HD_FR; ++f) {
+      const float xv = xs[f * (HD_K + 1) + tid];
+#pragma unroll
+      for (int c = 0; c < 2 * C; ++c) dwacc[c] = fmaf(dl[f * 2 * C + c], xv, dwacc[c]);
+    }
+    if (tid < 2 * C)
+      for (int f = 0; f < HD_FR; ++f) dbacc += dl[f * 2 * C + tid];
+  }
+#pragma unroll
+  for (int c = 0; c < 2 * C; ++c) dw_part[((size_t)b_ * 2 * C + c) * HD_K + tid] = dwacc[c];
+  if (tid < 2 * C) db_part[(size_t)b_ * 2 * C + tid] = dbacc;
+  // loss partials of this clip (plain sums; the host applies weights and 1/N)
+  float vals[4] = {l_s, l_w, l_cs, l_cw};
+  for (int i = 0; i < 4; ++i) {
+    __syncthreads();
+    lred[tid] = vals[i];
+    __syncthreads();
+    if (tid == 0) {
+      float s = 0.f;
+      for (int j = 0; j < HD_THREADS; ++j) s += lred[j];
+      loss_part[(size_t)b_ * 4 + i] = s;
+    }
+  }
+}
+
+extern "C" int bsed_head_fwd(const float* x, const float* w, const float* b, float* strong, float* sof_raw,
+                             float* weak, float* den, int B, int T, int K, int C, int attention, void* stream) {
+  BSED_CHECK_ARG(x && w && b && strong && sof_raw && weak && den, "bsed_head_fwd: null tensor");
+  BSED_CHECK_ARG(B > 0 && T > 0, "bsed_head_fwd: bad shape");
+  BSED_CHECK_ARG(K == HD_K && C == 20, "bsed_head_fwd: built for K=256, nclass=20 (got %d, %d)", K, C);
+  const size_t smem = (size_t)(2 * C * (HD_K + 1) + HD_FR * (HD_K + 1) + HD_FR * 2 * C + 2 * C + 2 * HD_FR * C) * 4;
+  static bool done = false;
+  if (!done) {
+    BSED_HIP(hipFuncSetAttribute((const void*)head_fwd_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+  }
+  hipLaunchKernelGGL(head_fwd_kernel<20>, dim3(B), dim3(HD_THREADS), smem, (hipStream_t)stream, x, w, b, strong,
+                     sof_raw, weak, den, T, attention);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_head_bwd(const BsedHeadBwdDesc* d, void* stream) {
+  BSED_CHECK_ARG(d, "bsed_head_bwd: null descriptor");
+  BSED_CHECK_ARG(d->x && d->w && d->strong && d->sof_raw && d->weak && d->den && d->dx && d->dw_part && d->db_part &&
+                     d->loss_part, "bsed_head_bwd: null tensor");
+  BSED_CHECK_ARG(d->B > 0 && d->T > 0 && d->K == HD_K && d->C == 20, "bsed_head_bwd: built for K=256, nclass=20");
+  const int C = 20;
+  const size_t smem = (size_t)(2 * C * (HD_K + 1) + HD_FR * (HD_K + 1) + HD_FR * 2 * C + 3 * C + HD_THREADS) * 4;
+  static bool done = false;
+  if (!done) {
+    BSED_HIP(hipFuncSetAttribute((const void*)head_bwd_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+  }
+  hipLaunchKernelGGL(head_bwd_kernel<20>, dim3(d->B), dim3(HD_THREADS), smem, (hipStream_t)stream, d->x, d->w,
+                     d->strong, d->sof_raw, d->weak, d->den, d->y_strong, d->y_weak, d->ema_strong, d->ema_weak,
+                     d->g_strong_ext, d->g_weak_ext, d->w_strong, d->w_weak, d->w_cons_s, d->w_cons_w, d->inv_n_strong,
+                     d->inv_n_weak, d->dx, d->dw_part, d->db_part, d->loss_part, d->T, d->attention);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}

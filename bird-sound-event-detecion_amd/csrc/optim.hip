@@ -1,0 +1,98 @@
+// Flat-buffer optimizer / EMA kernels: every parameter of CRNN + Predictor (+ discriminator) lives in one
+// contiguous fp32 arena, so one launch updates the whole model and one RCCL all-reduce moves all gradients.
+//
+//   adam_kernel          torch.optim.Adam(lr, betas, eps, weight_decay) step   [src/main_baseline.py:861-867]
+//   sgd_nesterov_kernel  torch.optim.SGD(momentum, nesterov=True, weight_decay) [src/main_scmt_ada_weak.py:854-866]
+//   ema_kernel           update_ema_variables: ema = ema*alpha + p*(1-alpha)    [src/main_baseline.py:91-105]
+#include "bsed_common.h"
+#include "../../include/bsed.h"
+#include <algorithm>
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
+                            float bc1, float bc2_sqrt, float gscale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+
+__global__ void sgd_nesterov_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n,
+                                    float lr, float momentum, float wd, int first, int nesterov, float gscale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    if (momentum != 0.f) {
+      const float bi = first ? gi : momentum * buf[i] + gi;
+      buf[i] = bi;
+      gi = nesterov ? gi + momentum * bi : bi;
+    }
+    p[i] = pi - lr * gi;
+  }
+}
+
+__global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, long n, float alpha) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    ema[i] = ema[i] * alpha + p[i] * (1.f - alpha);
+}
+
+// int64 state entries (BatchNorm num_batches_tracked): float math then truncation, as load_state_dict does
+__global__ void ema_i64_kernel(long long* __restrict__ ema, const long long* __restrict__ p, int n, float alpha) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ema[i] = (long long)((float)ema[i] * alpha + (float)p[i] * (1.f - alpha));
+}
+
+__global__ void scale_kernel(float* __restrict__ x, long n, float s) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= s;
+}
+
+static inline unsigned flat_grid(long n) { return (unsigned)std::min<long>(std::max<long>(ceil_div(n, 256), 1), 4096); }
+
+extern "C" int bsed_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, long step, float grad_scale, void* stream) {
+  BSED_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "bsed_adam_step: bad argument");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                     beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_sgd_step(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay,
+                             int first_step, int nesterov, float grad_scale, void* stream) {
+  BSED_CHECK_ARG(p && g && buf && n > 0, "bsed_sgd_step: bad argument");
+  hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, lr,
+                     momentum, weight_decay, first_step, nesterov, grad_scale);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_ema_update(float* ema, const float* p, long n, float alpha, void* stream) {
+  BSED_CHECK_ARG(ema && p && n > 0, "bsed_ema_update: bad argument");
+  hipLaunchKernelGGL(ema_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, ema, p, n, alpha);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_ema_update_i64(long long* ema, const long long* p, int n, float alpha, void* stream) {
+  BSED_CHECK_ARG(ema && p && n > 0, "bsed_ema_update_i64: bad argument");
+  hipLaunchKernelGGL(ema_i64_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, (hipStream_t)stream, ema, p, n, alpha);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_scale(float* x, long n, float s, void* stream) {
+  BSED_CHECK_ARG(x && n > 0, "bsed_scale: bad argument");
+  hipLaunchKernelGGL(scale_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, s);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}

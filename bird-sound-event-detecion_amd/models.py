@@ -1,0 +1,465 @@
+"""CRNN / Predictor with the reference's constructor signatures, state_dict keys and forward
+contracts, executed by hand-written HIP kernels (libbsed.so).
+
+    CRNN(n_in_channel, nclass, attention=False, activation="Relu", dropout=0, train_cnn=True,
+         rnn_type='BGRU', n_RNN_cell=64, n_layers_RNN=1, dropout_recurrent=0, cnn_integration=False,
+         learned_post=False, **cnn_kwargs)            reference src/models/CRNN_GRL.py:142-204
+    Predictor(nclass, attention=False, n_RNN_cell=64)  reference src/models/CRNN_GRL.py:430-460
+
+Differences that are deliberate:
+  * parameters are views into ONE flat fp32 arena per module (``.flat`` / ``.flat_grad``) so the optimizer,
+    the EMA update and the data-parallel all-reduce are single launches;
+  * activations are NHWC on the device; the (B,1,T,F) input and the (B,T',256) output have the
+    reference's layouts;
+  * dropout masks come from a counter RNG (Philox) keyed on ``(seed, layer)``: forward and backward
+    regenerate them instead of storing them.  Call ``set_seed(step)`` per step.
+Only the hot-path configuration is built: GLU activation, 3x3/stride-1/pad-1 convs, BGRU with 128 cells
+and 2 layers, 20 classes; anything else raises NotImplementedError (no silent fallback).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+
+BN_EPS = 1e-3
+BN_MOMENTUM = 0.99
+
+
+class _Holder(nn.Module):
+    """Parameter container (no forward): gives the reference's dotted state_dict names."""
+
+
+def _alloc_views(specs, device):
+    """specs: [(name, shape)] -> (flat tensor, {name: view})"""
+    total = sum(int(np.prod(s)) for _, s in specs)
+    flat = torch.zeros(total, device=device, dtype=torch.float32)
+    views, off = OrderedDict(), 0
+    for name, shape in specs:
+        n = int(np.prod(shape))
+        views[name] = (off, flat[off:off + n].view(shape))
+        off += n
+    return flat, views
+
+
+class _FlatModule(nn.Module):
+    """nn.Module whose parameters / float buffers are views of flat arenas."""
+
+    def _build(self, param_specs, buffer_specs, device):
+        self.flat, pviews = _alloc_views(param_specs, device)
+        self.flat_grad = torch.zeros_like(self.flat)
+        self.flat_buf, bviews = _alloc_views(buffer_specs, device) if buffer_specs else (None, OrderedDict())
+        self._poff = {k: v[0] for k, v in pviews.items()}
+        self._boff = {k: v[0] for k, v in bviews.items()}
+        for name, (off, view) in pviews.items():
+            p = nn.Parameter(view)
+            p.grad = self.flat_grad[off:off + view.numel()].view(view.shape)
+            self._register(name, p, True)
+        for name, (off, view) in bviews.items():
+            self._register(name, view, False)
+
+    def _register(self, dotted, tensor, is_param):
+        parts = dotted.split(".")
+        mod = self
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, _Holder())
+            mod = getattr(mod, p)
+        if is_param:
+            mod.register_parameter(parts[-1], tensor)
+        else:
+            mod.register_buffer(parts[-1], tensor)
+
+    def P(self, dotted):
+        mod = self
+        for p in dotted.split("."):
+            mod = getattr(mod, p)
+        return mod
+
+    def G(self, dotted):
+        return self.P(dotted).grad
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()
+        self._attach_grads()
+
+    def _attach_grads(self):
+        """(Re)bind every parameter's .grad to its slice of flat_grad.  torch optimizers' zero_grad(set_to_none=
+        True) drops the bindings; in that case the arena is cleared first, which is what the caller asked for."""
+        params = list(self.named_parameters())
+        if params and params[0][1].grad is None:
+            self.flat_grad.zero_()
+        for name, p in params:
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * self._poff[name]:
+                off = self._poff[name]
+                p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
+
+    def _apply(self, fn, recurse=True):
+        # parameters are views of a flat arena allocated on the GPU: moving them would break the views
+        probe = fn(torch.zeros(1, device=self.flat.device))
+        if probe.device != self.flat.device or probe.dtype != torch.float32:
+            raise L.BsedError("bsed_amd modules live on the GPU in fp32; .to()/.cpu()/.half() are not supported")
+        return self
+
+
+def _check_cfg(cond, what):
+    if not cond:
+        raise NotImplementedError(f"bsed_amd builds only the reference hot-path configuration: {what}")
+
+
+class CRNN(_FlatModule):
+    def __init__(self, n_in_channel, nclass, attention=False, activation="Relu", dropout=0, train_cnn=True,
+                 rnn_type="BGRU", n_RNN_cell=64, n_layers_RNN=1, dropout_recurrent=0, cnn_integration=False,
+                 learned_post=False, kernel_size=(3, 3, 3), padding=(1, 1, 1), stride=(1, 1, 1),
+                 nb_filters=(64, 64, 64), pooling=((1, 4), (1, 4), (1, 4)), device="cuda"):
+        super().__init__()
+        L._require_gpu()
+        _check_cfg(n_in_channel == 1 and not cnn_integration, "n_in_channel=1")
+        _check_cfg(activation.lower() == "glu", 'activation="glu"')
+        _check_cfg(rnn_type == "BGRU" and n_RNN_cell == 128 and n_layers_RNN == 2 and dropout_recurrent == 0,
+                   "BGRU, 128 cells, 2 layers, no recurrent dropout")
+        _check_cfg(all(k == 3 for k in kernel_size) and all(p == 1 for p in padding) and all(s == 1 for s in stride),
+                   "3x3 / stride 1 / pad 1 convolutions")
+        nb_filters = list(nb_filters)
+        _check_cfg(nb_filters[0] in (16, 32) and all(f in (16, 32, 64, 128) for f in nb_filters)
+                   and nb_filters[-1] == 128, "filters in {16,32,64,128}, last 128")
+        pooling = [tuple(p) for p in pooling]
+        _check_cfg(all(p in ((2, 2), (1, 2), (1, 1), (2, 1)) for p in pooling), "pooling windows of 1 or 2")
+        self.n_in_channel, self.attention, self.rnn_type = n_in_channel, attention, rnn_type
+        self.cnn_integration, self.train_cnn = cnn_integration, train_cnn
+        self.nb_filters, self.pooling, self.dropout_p = nb_filters, pooling, float(dropout)
+        self.n_hidden = n_RNN_cell
+        self.seed = 0
+        pspecs, bspecs = [], []
+        cin = 1
+        for i, co in enumerate(nb_filters):
+            pspecs += [(f"cnn.conv{i}.weight", (co, cin, 3, 3)), (f"cnn.conv{i}.bias", (co,)),
+                       (f"cnn.batchnorm{i}.weight", (co,)), (f"cnn.batchnorm{i}.bias", (co,)),
+                       (f"cnn.glu{i}.linear.weight", (co, co)), (f"cnn.glu{i}.linear.bias", (co,))]
+            bspecs += [(f"cnn.batchnorm{i}.running_mean", (co,)), (f"cnn.batchnorm{i}.running_var", (co,))]
+            cin = co
+        H = n_RNN_cell
+        for l in range(2):
+            nin = nb_filters[-1] if l == 0 else 2 * H
+            # forward and reverse tensors are adjacent so (768, nin) / (2,384,128) views cover both directions
+            pspecs += [(f"rnn.rnn.weight_ih_l{l}", (3 * H, nin)), (f"rnn.rnn.weight_ih_l{l}_reverse", (3 * H, nin)),
+                       (f"rnn.rnn.weight_hh_l{l}", (3 * H, H)), (f"rnn.rnn.weight_hh_l{l}_reverse", (3 * H, H)),
+                       (f"rnn.rnn.bias_ih_l{l}", (3 * H,)), (f"rnn.rnn.bias_ih_l{l}_reverse", (3 * H,)),
+                       (f"rnn.rnn.bias_hh_l{l}", (3 * H,)), (f"rnn.rnn.bias_hh_l{l}_reverse", (3 * H,))]
+        self._build(pspecs, bspecs, device)
+        self.nbt = torch.zeros(len(nb_filters), device=device, dtype=torch.int64)
+        for i in range(len(nb_filters)):
+            self.P(f"cnn.batchnorm{i}").register_buffer("num_batches_tracked", self.nbt[i])
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------ init / state
+    @torch.no_grad()
+    def reset_parameters(self):
+        """PyTorch default init (what the reference modules have before weights_init is applied)."""
+        for name, p in self.named_parameters():
+            if "batchnorm" in name:
+                p.fill_(1.0 if name.endswith("weight") else 0.0)
+            elif name.startswith("rnn"):
+                p.uniform_(-1 / math.sqrt(self.n_hidden), 1 / math.sqrt(self.n_hidden))
+            elif name.endswith("weight"):
+                fan_in = p[0].numel()
+                p.uniform_(-1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+            else:
+                w = self.P(name[:-4] + "weight")
+                fan_in = w[0].numel()
+                p.uniform_(-1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+        for name, b in self.named_buffers():
+            if name.endswith("running_var"):
+                b.fill_(1.0)
+            else:
+                b.zero_()
+
+    def set_seed(self, seed):
+        self.seed = int(seed)
+
+    def load_state_dict(self, state_dict, strict=True):
+        # reference checkpoints carry "cnn.conv0.weight"; its loaders rewrite to "cnn.cnn." (save_features.py:48-52)
+        sd = OrderedDict((k.replace("cnn.cnn.", "cnn.", 1) if k.startswith("cnn.cnn.") else k, v)
+                         for k, v in state_dict.items())
+        own = self.state_dict()
+        missing = [k for k in own if k not in sd]
+        unexpected = [k for k in sd if k not in own]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing}, unexpected {unexpected}")
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k in own:
+                    own[k].copy_(torch.as_tensor(v).to(own[k].device))
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    # ------------------------------------------------------------------ forward
+    def _rnn_views(self, l):
+        H = self.n_hidden
+        nin = self.nb_filters[-1] if l == 0 else 2 * H
+        o = self._poff
+        w_ih = self.flat[o[f"rnn.rnn.weight_ih_l{l}"]:o[f"rnn.rnn.weight_ih_l{l}"] + 6 * H * nin]
+        w_hh = self.flat[o[f"rnn.rnn.weight_hh_l{l}"]:o[f"rnn.rnn.weight_hh_l{l}"] + 6 * H * H]
+        b_ih = self.flat[o[f"rnn.rnn.bias_ih_l{l}"]:o[f"rnn.rnn.bias_ih_l{l}"] + 6 * H]
+        b_hh = self.flat[o[f"rnn.rnn.bias_hh_l{l}"]:o[f"rnn.rnn.bias_hh_l{l}"] + 6 * H]
+        return nin, w_ih, w_hh, b_ih, b_hh
+
+    def _rnn_grads(self, l):
+        H = self.n_hidden
+        nin = self.nb_filters[-1] if l == 0 else 2 * H
+        o, g = self._poff, self.flat_grad
+        return (g[o[f"rnn.rnn.weight_ih_l{l}"]:o[f"rnn.rnn.weight_ih_l{l}"] + 6 * H * nin],
+                g[o[f"rnn.rnn.weight_hh_l{l}"]:o[f"rnn.rnn.weight_hh_l{l}"] + 6 * H * H],
+                g[o[f"rnn.rnn.bias_ih_l{l}"]:o[f"rnn.rnn.bias_ih_l{l}"] + 6 * H],
+                g[o[f"rnn.rnn.bias_hh_l{l}"]:o[f"rnn.rnn.bias_hh_l{l}"] + 6 * H])
+
+    def run_forward(self, x, save=True):
+        """x: (B,1,T,F) fp32 GPU tensor.  Returns (enc (B,T',256), ctx for run_backward or None)."""
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise L.BsedError(f"CRNN expects (B,1,T,F), got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        B, _, Hh, Ww = x.shape
+        train = self.training
+        drop = self.dropout_p if train else 0.0
+        ctx = {"B": B, "blocks": [], "train": train, "seed": self.seed, "x": x} if save else None
+        a, cin = x, 1
+        for i, co in enumerate(self.nb_filters):
+            ph, pw = self.pooling[i]
+            if Ww % pw or Ww < 2 and pw > 1:
+                raise L.BsedError(f"block {i}: width {Ww} not divisible by the pooling window")
+            cw, cb = self.P(f"cnn.conv{i}.weight"), self.P(f"cnn.conv{i}.bias")
+            if i == 0:
+                y, stats = ops.conv0_fwd(a, cw, cb, B, Hh, Ww, co, want_stats=train)
+            else:
+                wpk = ops.pack_weight(cw, 9, cin, co, 1, 9, cin * 9)
+                y, stats = ops.igemm(a, wpk, co, B, Hh, Ww, cin, taps=ops.TAPS3x3, bias=cb,
+                                     epilogue=ops.EPI_STATS if train else ops.EPI_PLAIN)
+            bn = self.P(f"cnn.batchnorm{i}")
+            if train:
+                mean, invstd, scale, shift = ops.bn_finalize(stats, co, float(B * Hh * Ww), BN_EPS, BN_MOMENTUM,
+                                                             bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                                             self.nbt[i:i + 1])
+            else:
+                mean = invstd = None
+                scale, shift = ops.bn_eval(co, BN_EPS, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+            glu = self.P(f"cnn.glu{i}.linear")
+            wg = ops.pack_weight(glu.weight, 1, co, co, 0, 1, co)
+            pooled, _ = ops.igemm(y, wg, co, B, Hh, Ww, co, bias=glu.bias, epilogue=ops.EPI_GLU_POOL, a_scale=scale,
+                                  a_shift=shift, e_src=y, e_scale=scale, e_shift=shift, pool=(ph, pw), drop_p=drop,
+                                  rng_stream=100 + i, seed=self.seed)
+            if save:
+                ctx["blocks"].append(dict(inp=a, y=y, mean=mean, invstd=invstd, scale=scale, shift=shift, H=Hh, W=Ww,
+                                          cin=cin, co=co, pool=(ph, pw)))
+            a, cin = pooled, co
+            Hh, Ww = Hh // ph, Ww // pw
+        if Ww != 1:
+            raise L.BsedError(f"frequency axis must pool down to 1, got {Ww}")
+        T = Hh
+        seq = a.view(B, T, cin)
+        layers = []
+        for l in range(2):
+            nin, w_ih, w_hh, b_ih, b_hh = self._rnn_views(l)
+            wpk = ops.pack_weight(w_ih, 1, nin, 768, 0, 1, nin)
+            xp, _ = ops.igemm(seq, wpk, 768, 1, B * T, 1, nin, bias=b_ih)
+            out, gates = ops.gru_fwd(xp.view(B, T, 768), w_hh, b_hh, B, T, save_gates=save)
+            layers.append(dict(inp=seq, out=out, gates=gates))
+            seq = out
+        enc = ops.dropout(seq, drop, 200, self.seed) if drop > 0 else seq
+        if save:
+            ctx.update(T=T, layers=layers, drop=drop)
+        return enc, ctx
+
+    # ------------------------------------------------------------------ backward
+    def run_backward(self, ctx, d_enc):
+        """Accumulates parameter gradients into ``flat_grad``; returns nothing (the input needs no grad)."""
+        B, T = ctx["B"], ctx["T"]
+        seed = ctx["seed"]
+        d = d_enc.contiguous()
+        if ctx["drop"] > 0:
+            d = ops.dropout(d, ctx["drop"], 200, seed)
+        for l in (1, 0):
+            nin, w_ih, w_hh, b_ih, b_hh = self._rnn_views(l)
+            g_wih, g_whh, g_bih, g_bhh = self._rnn_grads(l)
+            lay = ctx["layers"][l]
+            dxp, dgh = ops.gru_bwd(d, lay["out"], lay["gates"], w_hh, B, T)
+            ops.colsum(dxp, B * T, 768, 768, g_bih)
+            ops.colsum(dgh, B * T, 768, 768, g_bhh)
+            part, G, KP, NP = ops.wgrad(lay["inp"], dxp, 1, B * T, 1, nin, 768)
+            ops.reduce_partials(part, G, 1, KP, NP, nin, 768, g_wih, 0, 1, nin)
+            for dr in range(2):
+                part, G, KP, NP = ops.wgrad(lay["out"], dgh, B, T, 1, 128, 384, taps=((-1 if dr == 0 else 1, 0),),
+                                            in_pitch=256, dy_pitch=768, in_offset=dr * 128, dy_offset=dr * 384)
+                ops.reduce_partials(part, G, 1, KP, NP, 128, 384, g_whh, 0, 1, 128, dst_offset=dr * 384 * 128)
+            wpk = ops.pack_weight(w_ih, 1, 768, nin, 0, nin, 1)
+            d, _ = ops.igemm(dxp, wpk, nin, 1, B * T, 1, 768)
+            d = d.view(B, T, nin)
+        if not self.train_cnn:
+            return
+        dpool = d.view(B, T, 1, self.nb_filters[-1])
+        for i in range(len(self.nb_filters) - 1, -1, -1):
+            blk = ctx["blocks"][i]
+            Hh, Ww, cin, co = blk["H"], blk["W"], blk["cin"], blk["co"]
+            ph, pw = blk["pool"]
+            y = blk["y"]
+            glu = self.P(f"cnn.glu{i}.linear")
+            bn = self.P(f"cnn.batchnorm{i}")
+            # (1) recompute lin, form d_lin and the gate-branch term
+            wg = ops.pack_weight(glu.weight, 1, co, co, 0, 1, co)
+            tt = torch.empty_like(y)
+            dlin, st = ops.igemm(y, wg, co, B, Hh, Ww, co, bias=glu.bias, epilogue=ops.EPI_GLU_BWD,
+                                 a_scale=blk["scale"], a_shift=blk["shift"], e_src=y, e_scale=blk["scale"],
+                                 e_shift=blk["shift"], e_dpool=dpool, out2=tt, pool=(ph, pw), drop_p=ctx["drop"] if ctx["train"] else 0.0,
+                                 rng_stream=100 + i, seed=seed)
+            ops.stats_to_grad(st, co, 0, glu.bias.grad)
+            # (2) dW_glu = d_lin^T @ bn(y)
+            part, G, KP, NP = ops.wgrad(y, dlin, B, Hh, Ww, co, co, a_scale=blk["scale"], a_shift=blk["shift"])
+            ops.reduce_partials(part, G, 1, KP, NP, co, co, glu.weight.grad, 0, 1, co)
+            # (3) g = d_lin @ W_glu + gate term  (gradient w.r.t. the BatchNorm output), with BN-backward sums
+            wgT = ops.pack_weight(glu.weight, 1, co, co, 0, co, 1)
+            g, st2 = ops.igemm(dlin, wgT, co, B, Hh, Ww, co, epilogue=ops.EPI_ADD_STATS2, out=tt, out2=tt, e_src=y)
+            # (4) BatchNorm backward -> d_y in place
+            ops.bn_bwd(st2, co, float(B * Hh * Ww), bn.weight, blk["mean"], blk["invstd"], bn.weight.grad,
+                       bn.bias.grad, g, y)
+            dy = g
+            cw = self.P(f"cnn.conv{i}.weight")
+            # conv bias feeds a train-mode BatchNorm: its gradient is exactly zero, leave it
+            if i == 0:
+                part, G = ops.conv0_wgrad(blk["inp"], dy, B, Hh, Ww, co)
+                ops.reduce_partials(part, G, 9, 1, co, 1, co, cw.grad, 1, 9, 9)
+            else:
+                part, G, KP, NP = ops.wgrad(blk["inp"], dy, B, Hh, Ww, cin, co, taps=ops.TAPS3x3)
+                ops.reduce_partials(part, G, 9, KP, NP, cin, co, cw.grad, 1, 9, cin * 9)
+                wd = ops.pack_weight(cw, 9, co, cin, 1, cin * 9, 9)
+                dpool, _ = ops.igemm(dy, wd, cin, B, Hh, Ww, co, taps=[(-a, -b) for a, b in ops.TAPS3x3])
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and self.training:
+            enc = _CRNNFunction.apply(x, self, self.P("cnn.conv0.weight"))
+        else:
+            enc, _ = self.run_forward(x, save=False)
+        return enc, enc
+
+
+class _CRNNFunction(torch.autograd.Function):
+    """autograd bridge so reference-style drivers (loss.backward(); optimizer.step()) keep working."""
+
+    @staticmethod
+    def forward(ctx, x, module, flat):
+        enc, c = module.run_forward(x, save=True)
+        ctx.module, ctx.c = module, c
+        return enc
+
+    @staticmethod
+    def backward(ctx, d_enc):
+        ctx.module._attach_grads()
+        ctx.module.run_backward(ctx.c, d_enc)
+        ctx.c = None
+        return None, None, None
+
+
+class Predictor(_FlatModule):
+    def __init__(self, nclass, attention=False, n_RNN_cell=64, device="cuda", **kwargs):
+        super().__init__()
+        L._require_gpu()
+        _check_cfg(nclass == 20 and n_RNN_cell == 128, "nclass=20, n_RNN_cell=128")
+        self.attention, self.nclass, self.K = attention, nclass, 2 * n_RNN_cell
+        # dense / dense_softmax rows are adjacent: one (2C, K) matrix for the fused head kernel
+        pspecs = [("dense.weight", (nclass, self.K)), ("dense_softmax.weight", (nclass, self.K)),
+                  ("dense.bias", (nclass,)), ("dense_softmax.bias", (nclass,))]
+        self._build(pspecs, [], device)
+        if not attention:
+            # the reference has no dense_softmax without attention: keep the tensors out of the state dict
+            del self.dense_softmax
+        self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self):
+        b = 1 / math.sqrt(self.K)
+        self.flat.uniform_(-b, b)
+
+    def _wb(self):
+        C, K = self.nclass, self.K
+        return self.flat[:2 * C * K], self.flat[2 * C * K:]
+
+    def run_forward(self, x):
+        x = x.contiguous()
+        B, T, K = x.shape
+        w, b = self._wb()
+        return ops.head_fwd(x, w, b, B, T, K, self.nclass, self.attention)
+
+    def run_backward(self, x, saved, **loss_kw):
+        """saved = (strong, sof, weak, den) from run_forward.  Accumulates dW/db, returns (dx, loss_part)."""
+        B, T, K = x.shape
+        C = self.nclass
+        w, _ = self._wb()
+        strong, sof, weak, den = saved
+        dx, dw_part, db_part, loss_part = ops.head_bwd(x.contiguous(), w, strong, sof, weak, den, B, T, K, C,
+                                                       self.attention, **loss_kw)
+        ops.reduce_partials(dw_part, B, 1, 2 * C, K, 2 * C, K, self.flat_grad, 0, K, 1)
+        ops.colsum(db_part, B, 2 * C, 2 * C, self.flat_grad[2 * C * K:])
+        return dx, loss_part
+
+    def forward(self, x, inference=False):
+        if torch.is_grad_enabled() and (x.requires_grad or self.training):
+            strong, weak = _PredictorFunction.apply(x, self, self.dense.weight)
+        else:
+            strong, _, weak, _ = self.run_forward(x)
+        if inference:
+            # reference CRNN_GRL.py:452-457 (hard-codes 313 frames there; any T here)
+            strong = strong * (weak > 0.5).float().unsqueeze(1)
+        return strong, weak
+
+
+class _PredictorFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module, flat):
+        strong, sof, weak, den = module.run_forward(x)
+        ctx.module = module
+        ctx.save_for_backward(x, strong, sof, weak, den)
+        return strong, weak
+
+    @staticmethod
+    def backward(ctx, g_strong, g_weak):
+        x, strong, sof, weak, den = ctx.saved_tensors
+        B, T, C = strong.shape
+        gs = g_strong.contiguous() if g_strong is not None else torch.zeros_like(strong)
+        gw = g_weak.contiguous() if g_weak is not None else torch.zeros_like(weak)
+        ctx.module._attach_grads()
+        dx, _ = ctx.module.run_backward(x, (strong, sof, weak, den), g_strong=gs, g_weak=gw, w_strong=0.0,
+                                        w_weak=0.0)
+        return dx, None, None
+
+
+def weights_init(m):
+    """Reference ``weights_init`` (src/utilities/utils.py:40-63) applied to a bsed_amd CRNN / Predictor:
+    xavier-uniform(gain sqrt2) convs with zero bias, BN ~ N(1, 0.02) / 0, orthogonal GRU matrices,
+    N(0, 0.01) Linear weights with zero bias (this includes the GLU's Linear)."""
+    if not isinstance(m, (CRNN, Predictor)):
+        return
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if ".conv" in name:
+                if name.endswith("weight"):
+                    t = torch.empty(p.shape)
+                    nn.init.xavier_uniform_(t, gain=np.sqrt(2))
+                    p.copy_(t)
+                else:
+                    p.zero_()
+            elif "batchnorm" in name:
+                if name.endswith("weight"):
+                    p.copy_(torch.empty(p.shape).normal_(1.0, 0.02))
+                else:
+                    p.zero_()
+            elif name.startswith("rnn"):
+                if p.dim() > 1:
+                    t = torch.empty(p.shape)
+                    nn.init.orthogonal_(t)
+                    p.copy_(t)
+            else:  # Linear: GLU linear, dense, dense_softmax
+                if name.endswith("weight"):
+                    p.copy_(torch.empty(p.shape).normal_(0, 0.01))
+                else:
+                    p.zero_()

@@ -1,0 +1,281 @@
+"""Thin typed wrappers over the kernel-level C ABI (include/bsed.h).  No math happens here: every
+function fills a descriptor with device pointers / shapes and launches HIP kernels on the current
+stream.  Activations are NHWC fp32 tensors."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+EPI_PLAIN, EPI_STATS, EPI_GLU_POOL, EPI_GLU_BWD, EPI_ADD_STATS2 = range(5)
+
+_fp = ctypes.c_void_p
+_i = ctypes.c_int
+
+
+class IgemmDesc(ctypes.Structure):
+    _fields_ = ([(n, _fp) for n in ("in_", "w", "bias", "out", "out2", "stats", "a_scale", "a_shift", "e_src",
+                                    "e_scale", "e_shift", "e_dpool")]
+                + [(n, _i) for n in ("in_pitch", "out_pitch", "e_pitch", "NB", "H", "W", "CIN", "N", "NP", "TH", "TW",
+                                     "tilesH", "tilesW", "hh", "hw", "ntaps")]
+                + [("dh", _i * 9), ("dw", _i * 9)]
+                + [(n, _i) for n in ("ph", "pw", "Hp", "Wp", "epilogue")]
+                + [("drop_p", ctypes.c_float), ("rng_stream", ctypes.c_uint32), ("seed", ctypes.c_uint64)])
+
+
+class WgradDesc(ctypes.Structure):
+    _fields_ = ([(n, _fp) for n in ("in_", "dy", "part", "a_scale", "a_shift")]
+                + [(n, _i) for n in ("in_pitch", "dy_pitch", "NB", "H", "W", "CIN", "CINP", "N", "NP", "G", "TH", "TW",
+                                     "tilesH", "tilesW", "hh", "hw", "ntaps")]
+                + [("dh", _i * 9), ("dw", _i * 9)])
+
+
+class HeadBwdDesc(ctypes.Structure):
+    _fields_ = ([(n, _fp) for n in ("x", "w", "strong", "sof_raw", "weak", "den", "y_strong", "y_weak", "ema_strong",
+                                    "ema_weak", "g_strong_ext", "g_weak_ext")]
+                + [(n, ctypes.c_float) for n in ("w_strong", "w_weak", "w_cons_s", "w_cons_w", "inv_n_strong",
+                                                 "inv_n_weak")]
+                + [(n, _fp) for n in ("dx", "dw_part", "db_part", "loss_part")]
+                + [(n, _i) for n in ("B", "T", "K", "C", "attention")])
+
+
+TAPS3x3 = [(kh - 1, kw - 1) for kh in range(3) for kw in range(3)]
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def tile_for(W):
+    tw = min(W, 16)
+    return 128 // tw, tw
+
+
+def _p(t):
+    return L.ptr(t).value if t is not None else None
+
+
+def _dp(t, offset=0):
+    """device pointer (int) of tensor storage + element offset; tensor need not be contiguous as a whole"""
+    return None if t is None else t.data_ptr() + 4 * offset
+
+
+def pack_weight(src, ntaps, K, N, s_tap, s_k, s_n, src_offset=0):
+    NP = round_up(N, 32)
+    dst = torch.empty((ntaps, K, NP), device=src.device, dtype=torch.float32)
+    L.call("bsed_pack_weight", _fp(_dp(src, src_offset)), L.ptr(dst), _i(ntaps), _i(K), _i(N), _i(NP),
+           ctypes.c_long(s_tap), ctypes.c_long(s_k), ctypes.c_long(s_n), L.stream())
+    return dst
+
+
+def igemm(inp, wpk, N, NB, H, W, CIN, taps=((0, 0),), bias=None, out=None, epilogue=EPI_PLAIN, in_pitch=None,
+          out_pitch=None, a_scale=None, a_shift=None, e_src=None, e_scale=None, e_shift=None, e_dpool=None,
+          out2=None, pool=(1, 1), drop_p=0.0, rng_stream=0, seed=0, in_offset=0, want_stats=False):
+    """Launch the implicit GEMM.  Returns (out, stats or None)."""
+    d = IgemmDesc()
+    TH, TW = tile_for(W)
+    NP = wpk.shape[2]
+    ph, pw = pool
+    Hp, Wp = H // ph, W // pw
+    dev = inp.device
+    if out is None:
+        shape = (NB, Hp, Wp, N) if epilogue == EPI_GLU_POOL else (NB, H, W, N)
+        out = torch.empty(shape, device=dev, dtype=torch.float32)
+    ntiles = NB * ((H + TH - 1) // TH) * (W // TW)
+    stats = None
+    if epilogue in (EPI_STATS, EPI_GLU_BWD, EPI_ADD_STATS2):
+        stats = torch.empty((ntiles, 2, N), device=dev, dtype=torch.float32)
+    d.in_ = _dp(inp, in_offset); d.w = _p(wpk); d.bias = _p(bias); d.out = _p(out); d.out2 = _p(out2)
+    d.stats = _p(stats); d.a_scale = _p(a_scale); d.a_shift = _p(a_shift); d.e_src = _p(e_src)
+    d.e_scale = _p(e_scale); d.e_shift = _p(e_shift); d.e_dpool = _p(e_dpool)
+    d.in_pitch = CIN if in_pitch is None else in_pitch
+    d.out_pitch = N if out_pitch is None else out_pitch
+    d.e_pitch = N
+    d.NB, d.H, d.W, d.CIN, d.N, d.NP = NB, H, W, CIN, N, NP
+    d.TH, d.TW = TH, TW
+    d.hh = max(abs(t[0]) for t in taps); d.hw = max(abs(t[1]) for t in taps)
+    d.ntaps = len(taps)
+    for i, (a, b) in enumerate(taps):
+        d.dh[i], d.dw[i] = a, b
+    d.ph, d.pw, d.Hp, d.Wp = ph, pw, Hp, Wp
+    d.epilogue = epilogue
+    d.drop_p, d.rng_stream, d.seed = drop_p, rng_stream, seed
+    L.call("bsed_igemm", ctypes.byref(d), L.stream())
+    return out, stats
+
+
+def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=None, a_scale=None, a_shift=None,
+          in_offset=0, dy_offset=0):
+    """Partial slabs of dW; returns (part, G, CINP, NP)."""
+    d = WgradDesc()
+    TH, TW = tile_for(W)
+    CINP, NP = round_up(CIN, 32), round_up(N, 32)
+    ntiles = NB * ((H + TH - 1) // TH) * (W // TW)
+    G = max(1, min(ntiles, 1024 // (NP // 32)))
+    part = torch.empty((G, len(taps), CINP, NP), device=inp.device, dtype=torch.float32)
+    d.in_ = _dp(inp, in_offset); d.dy = _dp(dy, dy_offset); d.part = _p(part)
+    d.a_scale = _p(a_scale); d.a_shift = _p(a_shift)
+    d.in_pitch = CIN if in_pitch is None else in_pitch
+    d.dy_pitch = N if dy_pitch is None else dy_pitch
+    d.NB, d.H, d.W, d.CIN, d.CINP, d.N, d.NP, d.G = NB, H, W, CIN, CINP, N, NP, G
+    d.TH, d.TW = TH, TW
+    d.hh = max(abs(t[0]) for t in taps); d.hw = max(abs(t[1]) for t in taps)
+    d.ntaps = len(taps)
+    for i, (a, b) in enumerate(taps):
+        d.dh[i], d.dw[i] = a, b
+    L.call("bsed_wgrad", ctypes.byref(d), L.stream())
+    return part, G, CINP, NP
+
+
+def reduce_partials(part, G, ntaps, KP, NP, K, N, dst, s_tap, s_k, s_n, accumulate=True, dst_offset=0):
+    L.call("bsed_reduce_partials", L.ptr(part), _i(G), _i(ntaps), _i(KP), _i(NP), _i(K), _i(N),
+           _fp(_dp(dst, dst_offset)), ctypes.c_long(s_tap), ctypes.c_long(s_k), ctypes.c_long(s_n),
+           _i(1 if accumulate else 0), L.stream())
+
+
+_scratch = {}
+
+
+def stats_scratch(C, device):
+    key = (C, str(device))
+    s = _scratch.get(key)
+    if s is None:
+        n = L.lib().bsed_stats_scratch_bytes
+        n.restype = ctypes.c_size_t
+        s = _scratch[key] = torch.empty((n(_i(C)) + 7) // 8, device=device, dtype=torch.float64)
+    return s
+
+
+def conv0_fwd(x, w, bias, NB, H, W, CO, want_stats):
+    y = torch.empty((NB, H, W, CO), device=x.device, dtype=torch.float32)
+    stats = None
+    nt = L.lib().bsed_conv0_num_tiles(NB, H, W)
+    if want_stats:
+        stats = torch.empty((nt, 2, CO), device=x.device, dtype=torch.float32)
+    L.call("bsed_conv0_fwd", L.ptr(x), _fp(_dp(w)), _fp(_dp(bias)), L.ptr(y), _fp(_p(stats)), _i(NB), _i(H), _i(W),
+           _i(CO), L.stream())
+    return y, stats
+
+
+def conv0_wgrad(x, dy, NB, H, W, CO):
+    G = min(1024, max(1, (NB * H * W) // 256))
+    part = torch.empty((G, 9, CO), device=x.device, dtype=torch.float32)
+    L.call("bsed_conv0_wgrad", L.ptr(x), L.ptr(dy), L.ptr(part), _i(G), _i(NB), _i(H), _i(W), _i(CO), L.stream())
+    return part, G
+
+
+def bn_finalize(stats, C, count, eps, momentum, gamma, beta, rmean, rvar, nbt):
+    dev = stats.device
+    mean, invstd, scale, shift = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(4))
+    L.call("bsed_bn_finalize", L.ptr(stats), ctypes.c_long(stats.shape[0]), _i(C), ctypes.c_double(count),
+           ctypes.c_float(eps), ctypes.c_float(momentum), _fp(_dp(gamma)), _fp(_dp(beta)), _fp(_dp(rmean)),
+           _fp(_dp(rvar)), _fp(None if nbt is None else nbt.data_ptr()), L.ptr(mean), L.ptr(invstd), L.ptr(scale),
+           L.ptr(shift), L.ptr(stats_scratch(C, dev), torch.float64), L.stream())
+    return mean, invstd, scale, shift
+
+
+def bn_eval(C, eps, gamma, beta, rmean, rvar):
+    dev = gamma.device
+    scale, shift = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(2))
+    L.call("bsed_bn_eval", _i(C), ctypes.c_float(eps), _fp(_dp(gamma)), _fp(_dp(beta)), _fp(_dp(rmean)),
+           _fp(_dp(rvar)), L.ptr(scale), L.ptr(shift), L.stream())
+    return scale, shift
+
+
+def bn_bwd(stats, C, count, gamma, mean, invstd, dgamma, dbeta, g_inout, y):
+    dev = y.device
+    coef = torch.empty((3, C), device=dev, dtype=torch.float32)
+    L.call("bsed_bn_bwd", L.ptr(stats), ctypes.c_long(stats.shape[0]), _i(C), ctypes.c_double(count), _fp(_dp(gamma)),
+           L.ptr(mean), L.ptr(invstd), _fp(_dp(dgamma)), _fp(_dp(dbeta)), _i(1), L.ptr(g_inout), L.ptr(y),
+           ctypes.c_long(y.numel()), L.ptr(coef), L.ptr(stats_scratch(C, dev), torch.float64), L.stream())
+
+
+def stats_to_grad(stats, C, which, dst):
+    L.call("bsed_stats_to_grad", L.ptr(stats), ctypes.c_long(stats.shape[0]), _i(C), _i(which), _fp(_dp(dst)), _i(1),
+           L.ptr(stats_scratch(C, stats.device), torch.float64), L.stream())
+
+
+def colsum(inp, M, C, pitch, dst, accumulate=True, in_offset=0):
+    G = int(min(512, M))
+    part = torch.empty((G, 2, C), device=inp.device, dtype=torch.float32)
+    L.call("bsed_colsum", _fp(_dp(inp, in_offset)), ctypes.c_long(M), _i(C), _i(pitch), L.ptr(part), _i(G),
+           _fp(_dp(dst)), _i(1 if accumulate else 0), L.ptr(stats_scratch(C, inp.device), torch.float64), L.stream())
+
+
+def dropout(x, p, rng_stream, seed):
+    out = torch.empty_like(x)
+    L.call("bsed_dropout", L.ptr(x), L.ptr(out), ctypes.c_long(x.numel()), ctypes.c_float(p),
+           ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream())
+    return out
+
+
+def gru_rows(B):
+    """rows per workgroup so that (B/R) x 2 directions fills the 256 CUs"""
+    return 1 if B * 2 <= 256 else 2
+
+
+def gru_fwd(xp, w_hh, b_hh, B, T, save_gates):
+    out = torch.empty((B, T, 256), device=xp.device, dtype=torch.float32)
+    gates = torch.empty((B, T, 2, 4, 128), device=xp.device, dtype=torch.float32) if save_gates else None
+    L.call("bsed_gru_fwd", L.ptr(xp), _fp(_dp(w_hh)), _fp(_dp(b_hh)), L.ptr(out), _fp(_p(gates)), _i(B), _i(T),
+           _i(gru_rows(B)), L.stream())
+    return out, gates
+
+
+def gru_bwd(dout, out, gates, w_hh, B, T):
+    dxp = torch.empty((B, T, 768), device=dout.device, dtype=torch.float32)
+    dgh = torch.empty((B, T, 768), device=dout.device, dtype=torch.float32)
+    L.call("bsed_gru_bwd", L.ptr(dout), L.ptr(out), L.ptr(gates), _fp(_dp(w_hh)), L.ptr(dxp), L.ptr(dgh), _i(B), _i(T),
+           _i(gru_rows(B)), L.stream())
+    return dxp, dgh
+
+
+def head_fwd(x, w, b, B, T, K, C, attention):
+    dev = x.device
+    strong = torch.empty((B, T, C), device=dev, dtype=torch.float32)
+    sof = torch.empty((B, T, C), device=dev, dtype=torch.float32)
+    weak = torch.empty((B, C), device=dev, dtype=torch.float32)
+    den = torch.empty((B, C), device=dev, dtype=torch.float32)
+    L.call("bsed_head_fwd", L.ptr(x), _fp(_dp(w)), _fp(_dp(b)), L.ptr(strong), L.ptr(sof), L.ptr(weak), L.ptr(den),
+           _i(B), _i(T), _i(K), _i(C), _i(1 if attention else 0), L.stream())
+    return strong, sof, weak, den
+
+
+def head_bwd(x, w, strong, sof, weak, den, B, T, K, C, attention, y_strong=None, y_weak=None, ema_strong=None,
+             ema_weak=None, g_strong=None, g_weak=None, w_strong=1.0, w_weak=1.0, w_cons_s=0.0, w_cons_w=0.0):
+    dev = x.device
+    d = HeadBwdDesc()
+    dx = torch.empty((B, T, K), device=dev, dtype=torch.float32)
+    dw_part = torch.empty((B, 2 * C, K), device=dev, dtype=torch.float32)
+    db_part = torch.empty((B, 2 * C), device=dev, dtype=torch.float32)
+    loss_part = torch.empty((B, 4), device=dev, dtype=torch.float32)
+    d.x = _p(x); d.w = _dp(w); d.strong = _p(strong); d.sof_raw = _p(sof); d.weak = _p(weak); d.den = _p(den)
+    d.y_strong = _p(y_strong); d.y_weak = _p(y_weak); d.ema_strong = _p(ema_strong); d.ema_weak = _p(ema_weak)
+    d.g_strong_ext = _p(g_strong); d.g_weak_ext = _p(g_weak)
+    d.w_strong, d.w_weak, d.w_cons_s, d.w_cons_w = w_strong, w_weak, w_cons_s, w_cons_w
+    d.inv_n_strong, d.inv_n_weak = 1.0 / (B * T * C), 1.0 / (B * C)
+    d.dx = _p(dx); d.dw_part = _p(dw_part); d.db_part = _p(db_part); d.loss_part = _p(loss_part)
+    d.B, d.T, d.K, d.C, d.attention = B, T, K, C, 1 if attention else 0
+    L.call("bsed_head_bwd", ctypes.byref(d), L.stream())
+    return dx, dw_part, db_part, loss_part
+
+
+def adam_step(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    L.call("bsed_adam_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), ctypes.c_long(p.numel()), ctypes.c_float(lr),
+           ctypes.c_float(betas[0]), ctypes.c_float(betas[1]), ctypes.c_float(eps), ctypes.c_float(weight_decay),
+           ctypes.c_long(step), ctypes.c_float(grad_scale), L.stream())
+
+
+def sgd_step(p, g, buf, lr, momentum, weight_decay, first_step, nesterov=True, grad_scale=1.0):
+    L.call("bsed_sgd_step", L.ptr(p), L.ptr(g), L.ptr(buf), ctypes.c_long(p.numel()), ctypes.c_float(lr),
+           ctypes.c_float(momentum), ctypes.c_float(weight_decay), _i(1 if first_step else 0),
+           _i(1 if nesterov else 0), ctypes.c_float(grad_scale), L.stream())
+
+
+def ema_update(ema, p, alpha):
+    L.call("bsed_ema_update", L.ptr(ema), L.ptr(p), ctypes.c_long(p.numel()), ctypes.c_float(alpha), L.stream())
+
+
+def ema_update_i64(ema, p, alpha):
+    L.call("bsed_ema_update_i64", L.ptr(ema, torch.int64), L.ptr(p, torch.int64), _i(p.numel()),
+           ctypes.c_float(alpha), L.stream())

@@ -62,6 +62,169 @@ int bsed_mel_db(const float* mel_lin, const float* clip_max, int B, int T, int T
                 float top_db, float* out_db, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM contraction on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+ *   out[p][n] = sum_{tap,k} in[p + (dh,dw)(tap)][k] * w[tap][k][n]      zero padding outside (H,W)
+ * One body, selected by `epilogue`, replaces the stock ATen/cuDNN ops the reference reaches through
+ *   nn.Conv2d 3x3 + train-mode BatchNorm2d statistics   (src/models/CNN.py:46-49)       BSED_EPI_STATS
+ *   GLU = Linear(C,C)(bn(x)) * sigmoid(bn(x)), Dropout, AvgPool2d (CNN.py:5-16,59-67)  BSED_EPI_GLU_POOL
+ *   their backward passes                                                BSED_EPI_GLU_BWD / _ADD_STATS2
+ *   nn.GRU input projections x @ W_ih^T and data gradients (src/models/RNN.py:12)      BSED_EPI_PLAIN
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+  BSED_EPI_PLAIN = 0,      /* out = acc + bias                                                        */
+  BSED_EPI_STATS = 1,      /* + per-tile (sum, sum of squares) per channel -> stats[tile][2][N]        */
+  BSED_EPI_GLU_POOL = 2,   /* out = avgpool(dropout((acc+bias) * sigmoid(e_src*e_scale+e_shift)))      */
+  BSED_EPI_GLU_BWD = 3,    /* out = d_lin, out2 = d_res*lin*sig*(1-sig); stats[tile][0][N] = sum d_lin */
+  BSED_EPI_ADD_STATS2 = 4  /* out = acc + out2; stats = (sum g, sum g*e_src)                           */
+};
+
+typedef struct BsedIgemmDesc {
+  const float* in;       /* (NB,H,W,in_pitch) NHWC; CIN <= in_pitch                                    */
+  const float* w;        /* packed (ntaps, CIN, NP) by bsed_pack_weight                                */
+  const float* bias;     /* (N) or NULL                                                                */
+  float* out;            /* (NB,H,W,out_pitch)  [GLU_POOL: (NB,Hp,Wp,out_pitch)]                       */
+  float* out2;           /* GLU_BWD: second output; ADD_STATS2: residual input (may alias out)         */
+  float* stats;          /* (num_tiles, 2, N) per-tile partial sums                                    */
+  const float* a_scale;  /* optional per-CIN affine applied while loading `in` (BatchNorm apply)       */
+  const float* a_shift;
+  const float* e_src;    /* epilogue side input (NB,H,W,e_pitch): pre-BN conv output                   */
+  const float* e_scale;  /* (N) BatchNorm scale/shift of the gate branch                               */
+  const float* e_shift;
+  const float* e_dpool;  /* GLU_BWD: gradient w.r.t. the pooled output (NB,Hp,Wp,N)                    */
+  int in_pitch, out_pitch, e_pitch;
+  int NB, H, W, CIN, N, NP;   /* NP = N rounded up to a multiple of 32 (weight row stride)            */
+  int TH, TW;                 /* spatial tile, TH*TW == 128, TW a power of two dividing W             */
+  int tilesH, tilesW;         /* filled by the library                                                 */
+  int hh, hw;                 /* halo rows / cols = max |dh| / |dw|                                    */
+  int ntaps, dh[9], dw[9];
+  int ph, pw, Hp, Wp;         /* pooling window and pooled extent (floor)                              */
+  int epilogue;
+  float drop_p;               /* dropout probability of the GLU epilogues (0 = off)                    */
+  uint32_t rng_stream;        /* Philox stream id (layer id)                                           */
+  uint64_t seed;
+} BsedIgemmDesc;
+
+int bsed_igemm(const BsedIgemmDesc* desc /*host*/, void* stream);
+int bsed_igemm_num_tiles(const BsedIgemmDesc* desc /*host*/);
+
+/* dW[tap][k][n] = sum_p in[p + (dh,dw)(tap)][k] * dy[p][n]: persistent workgroups over position tiles
+ * write partial slabs part[G][ntaps][CINP][NP]; bsed_reduce_partials sums them into the gradient. */
+typedef struct BsedWgradDesc {
+  const float* in;       /* (NB,H,W,in_pitch) */
+  const float* dy;       /* (NB,H,W,dy_pitch) */
+  float* part;           /* (G, ntaps, CINP, NP) */
+  const float* a_scale;  /* optional per-CIN affine on `in` */
+  const float* a_shift;
+  int in_pitch, dy_pitch;
+  int NB, H, W, CIN, CINP, N, NP, G;
+  int TH, TW, tilesH, tilesW, hh, hw;
+  int ntaps, dh[9], dw[9];
+} BsedWgradDesc;
+
+int bsed_wgrad(const BsedWgradDesc* desc /*host*/, void* stream);
+/* dst[tap*s_tap + k*s_k + n*s_n] (+)= sum_g part[g][tap][k][n]   (k < K, n < N) */
+int bsed_reduce_partials(const float* part, int G, int ntaps, int KP, int NP, int K, int N, float* dst,
+                         long s_tap, long s_k, long s_n, int accumulate, void* stream);
+/* dst[tap][k][n] = src[tap*s_tap + k*s_k + n*s_n], zero for N <= n < NP */
+int bsed_pack_weight(const float* src, float* dst, int ntaps, int K, int N, int NP, long s_tap, long s_k,
+                     long s_n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Streaming CNN pieces (csrc/cnn_ops.hip)
+ * ---------------------------------------------------------------------------------------------- */
+/* first conv, Cin = 1 (src/models/CNN.py:46-47 with i = 0): x (NB,H,W) -> y (NB,H,W,CO); w is the
+ * PyTorch (CO,1,3,3) tensor; stats (bsed_conv0_num_tiles, 2, CO) per-tile (sum, sumsq) or NULL. */
+int bsed_conv0_fwd(const float* x, const float* w, const float* bias, float* y, float* stats, int NB, int H,
+                   int W, int CO, void* stream);
+int bsed_conv0_num_tiles(int NB, int H, int W);
+/* dW of the first conv: part (G, 9, CO) partial slabs for bsed_reduce_partials */
+int bsed_conv0_wgrad(const float* x, const float* dy, float* part, int G, int NB, int H, int W, int CO,
+                     void* stream);
+/* fp64 scratch needed by the statistics reductions below */
+size_t bsed_stats_scratch_bytes(int C);
+/* BatchNorm2d(eps, momentum) in train mode (src/models/CNN.py:49): per-tile partials -> batch mean /
+ * invstd, scale = gamma*invstd, shift = beta - mean*scale; running stats (unbiased var) and
+ * num_batches_tracked are updated in place when given. count = NB*H*W. */
+int bsed_bn_finalize(const float* partial, long ntiles, int C, double count, float eps, float momentum,
+                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     long long* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                     void* scratch, void* stream);
+/* eval mode: scale/shift from the running statistics */
+int bsed_bn_eval(int C, float eps, const float* gamma, const float* beta, const float* running_mean,
+                 const float* running_var, float* scale, float* shift, void* stream);
+/* BatchNorm backward: partial = per-tile (sum g, sum g*y); writes dgamma/dbeta and turns g (n_elems,
+ * NHWC, in place) into d_y = A g + B (y - mean) + C;  coef is a (3,C) work buffer */
+int bsed_bn_bwd(const float* partial, long ntiles, int C, double count, const float* gamma, const float* mean,
+                const float* invstd, float* dgamma, float* dbeta, int accumulate, float* g_inout, const float* y,
+                long n_elems, float* coef, void* scratch, void* stream);
+/* dst[c] (+)= sum_tiles partial[tile][which][c] */
+int bsed_stats_to_grad(const float* partial, long ntiles, int C, int which, float* dst, int accumulate,
+                       void* scratch, void* stream);
+/* dst[c] (+)= sum_r in[r*pitch + c], r < M; part holds G*2*C floats */
+int bsed_colsum(const float* in, long M, int C, int pitch, float* part, int G, float* dst, int accumulate,
+                void* scratch, void* stream);
+/* nn.Dropout(p) with a stateless Philox mask: out = in * keep/(1-p); the same call is its backward */
+int bsed_dropout(const float* in, float* out, long n, float p, uint32_t rng_stream, uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Bidirectional GRU recurrence (csrc/gru.hip); replaces nn.GRU of src/models/RNN.py:7-16.
+ *   xp    (B,T,768)  x @ [W_ih; W_ih_reverse]^T + b_ih   (from bsed_igemm), [dir*384 + gate*128 + k]
+ *   w_hh  (2,384,128), b_hh (2,384)                       gate order r,z,n
+ *   out   (B,T,256)  [dir*128 + k];  gates (B,T,2,4,128) r,z,n,(W_hn h + b_hn) saved for backward
+ * ---------------------------------------------------------------------------------------------- */
+int bsed_gru_fwd(const float* xp, const float* w_hh, const float* b_hh, float* out, float* gates, int B, int T,
+                 int rows_per_wg, void* stream);
+/* BPTT: dxp = d(x-side pre-activations) (B,T,768), dgh = d(h-side pre-activations) (B,T,768) */
+int bsed_gru_bwd(const float* dout, const float* out, const float* gates, const float* w_hh, float* dxp,
+                 float* dgh, int B, int T, int rows_per_wg, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Predictor head + losses (csrc/head.hip); replaces Predictor.forward (src/models/CRNN_GRL.py:441-460)
+ * and the BCE / MSE loss assembly of train_mt (src/main_baseline.py:431-498).
+ *   w (2C,K): rows 0..C-1 = dense.weight, rows C..2C-1 = dense_softmax.weight; b (2C) likewise.
+ * ---------------------------------------------------------------------------------------------- */
+int bsed_head_fwd(const float* x, const float* w, const float* b, float* strong, float* sof_raw, float* weak,
+                  float* den, int B, int T, int K, int C, int attention, void* stream);
+
+typedef struct BsedHeadBwdDesc {
+  const float* x;            /* (B,T,K) encoder output */
+  const float* w;            /* (2C,K) */
+  const float* strong;       /* (B,T,C) saved by bsed_head_fwd */
+  const float* sof_raw;      /* (B,T,C) unclamped softmax */
+  const float* weak;         /* (B,C) */
+  const float* den;          /* (B,C) sum_t clamp(softmax) */
+  const float* y_strong;     /* (B,T,C) or NULL: BCE(strong, y) * w_strong */
+  const float* y_weak;       /* (B,C)   or NULL: BCE(weak, y)   * w_weak */
+  const float* ema_strong;   /* (B,T,C) or NULL: MSE(strong, ema) * w_cons_s */
+  const float* ema_weak;     /* (B,C)   or NULL: MSE(weak, ema)   * w_cons_w */
+  const float* g_strong_ext; /* (B,T,C) or NULL: upstream dL/dstrong (autograd drop-in path) */
+  const float* g_weak_ext;   /* (B,C)   or NULL */
+  float w_strong, w_weak, w_cons_s, w_cons_w;
+  float inv_n_strong, inv_n_weak; /* 1/(B*T*C), 1/(B*C): reduction='mean' */
+  float* dx;                 /* (B,T,K) */
+  float* dw_part;            /* (B,2C,K) per-clip partials for bsed_reduce_partials */
+  float* db_part;            /* (B,2C) */
+  float* loss_part;          /* (B,4): plain sums of BCE_strong, BCE_weak, SE_strong, SE_weak */
+  int B, T, K, C, attention;
+} BsedHeadBwdDesc;
+
+int bsed_head_bwd(const BsedHeadBwdDesc* desc /*host*/, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flat-arena optimizer / EMA (csrc/optim.hip)
+ * ---------------------------------------------------------------------------------------------- */
+/* torch.optim.Adam step (src/main_baseline.py:861-867); grad_scale multiplies g first (1/world_size) */
+int bsed_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, long step, float grad_scale, void* stream);
+/* torch.optim.SGD(momentum, nesterov, weight_decay) step (src/main_scmt_ada_weak.py:854-866) */
+int bsed_sgd_step(float* p, const float* g, float* buf, long n, float lr, float momentum, float weight_decay,
+                  int first_step, int nesterov, float grad_scale, void* stream);
+/* update_ema_variables (src/main_baseline.py:91-105): ema = ema*alpha + p*(1-alpha) */
+int bsed_ema_update(float* ema, const float* p, long n, float alpha, void* stream);
+int bsed_ema_update_i64(long long* ema, const long long* p, int n, float alpha, void* stream);
+int bsed_scale(float* x, long n, float s, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Self tests (used by tests/ only)
  * ---------------------------------------------------------------------------------------------- */
 /* C(32,32) = A(32,K) @ B(K,32) through one wave of v_mfma_f32_32x32x2_f32: pins the fragment maps */

@@ -1,0 +1,203 @@
+"""GPU parity of the CRNN + Predictor HIP path against the torch CPU oracle and the goldens produced
+by the reference (tests/golden/crnn_*.npz).
+
+Tolerances (fp32 MFMA vs fp32 CPU; north star: logits within 1e-4):
+  activations / logits : 1e-4 absolute (strong/weak probabilities 2e-5)
+  loss                 : 2e-5 relative
+  gradients            : per-tensor L2 error <= 2e-4 of the tensor's L2 norm (+1e-7)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import crnn_oracle as co
+from oracle import seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(dropout, seed):
+    kw = dict(co.CRNN_KWARGS)
+    kw["dropout"] = dropout
+    crnn, pred = co.CRNN(**kw), co.Predictor(**co.PREDICTOR_KWARGS)
+    seeded.load_seeded(crnn, seed)
+    seeded.load_seeded(pred, seed + 1)
+    return crnn, pred
+
+
+def _mine(dropout, ocrnn, opred):
+    from bsed_amd.models import CRNN, Predictor
+    kw = dict(co.CRNN_KWARGS)
+    kw["dropout"] = dropout
+    crnn, pred = CRNN(**kw), Predictor(**co.PREDICTOR_KWARGS)
+    crnn.load_state_dict(ocrnn.state_dict())
+    pred.load_state_dict(opred.state_dict())
+    return crnn, pred
+
+
+def _stages(ocrnn, x):
+    """oracle intermediates: conv outputs and pooled outputs per block (NHWC), GRU output"""
+    outs = {}
+    hooks = []
+    for name, mod in ocrnn.cnn.cnn.named_children():
+        if name.startswith("conv") or name.startswith("pooling"):
+            hooks.append(mod.register_forward_hook(
+                lambda m, i, o, name=name: outs.__setitem__(name, o.detach().permute(0, 2, 3, 1).contiguous())))
+    with torch.no_grad():
+        enc, _ = ocrnn(x)
+    for h in hooks:
+        h.remove()
+    return outs, enc
+
+
+def _report(ctx, outs):
+    rep = []
+    for i, blk in enumerate(ctx["blocks"]):
+        e_y = float((blk["y"].cpu() - outs[f"conv{i}"]).abs().max())
+        rep.append(f"conv{i}:{e_y:.2e}")
+        if i + 1 < len(ctx["blocks"]):
+            e_p = float((ctx["blocks"][i + 1]["inp"].cpu() - outs[f"pooling{i}"]).abs().max())
+            rep.append(f"pool{i}:{e_p:.2e}")
+    return " ".join(rep)
+
+
+@pytest.mark.parametrize("tag", ["small", "R"])
+def test_eval_forward_matches_oracle_and_golden(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"crnn_{tag}.npz"))
+    B, T, seed = (int(v) for v in g["meta"])
+    x = torch.from_numpy(seeded.db_like_input(seed + 10, B, T))
+    ocrnn, opred = _oracle(0.5, seed)
+    crnn, pred = _mine(0.5, ocrnn, opred)
+    ocrnn.eval(); opred.eval(); crnn.eval(); pred.eval()
+    outs, enc_ref = _stages(ocrnn, x)
+    enc, ctx = crnn.run_forward(x.cuda(), save=True)
+    rep = _report(ctx, outs)
+    err = float((enc.cpu() - enc_ref).abs().max())
+    assert err < 1e-4, (err, rep)
+    np.testing.assert_allclose(enc.cpu().numpy(), g["eval_enc"], atol=1e-4)
+    with torch.no_grad():
+        strong, weak = pred(enc)
+    np.testing.assert_allclose(strong.cpu().numpy(), g["eval_strong"], atol=2e-5)
+    np.testing.assert_allclose(weak.cpu().numpy(), g["eval_weak"], atol=2e-5)
+    # module-level drop-in call: (enc, d_input) both returned, inference flag masks by the weak decision
+    with torch.no_grad():
+        e1, e2 = crnn(x.cuda())
+        s_inf, w_inf = pred(e1, inference=True)
+    assert e1 is e2
+    assert torch.equal(s_inf, strong * (weak > 0.5).float().unsqueeze(1))
+
+
+def _grad_check(mine, ref_named, tol=2e-4):
+    bad = []
+    for name, gref in ref_named.items():
+        key = name.replace("cnn.cnn.", "cnn.", 1)
+        if ".conv" in key and key.endswith(".bias"):
+            continue  # exactly-zero gradient under train-mode BatchNorm; the oracle's value is round-off
+        got = mine.P(key).grad.detach().cpu().double()
+        ref = gref.double()
+        err = float((got - ref).norm())
+        if err > tol * float(ref.norm()) + 1e-7:
+            bad.append((key, err, float(ref.norm())))
+    return bad
+
+
+@pytest.mark.parametrize("tag", ["small", "R"])
+def test_train_forward_backward_matches_oracle(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"crnn_{tag}.npz"))
+    B, T, seed = (int(v) for v in g["meta"])
+    x = torch.from_numpy(seeded.db_like_input(seed + 10, B, T))
+    y = torch.from_numpy(seeded.strong_targets(seed + 11, B, T // 4))
+    ocrnn, opred = _oracle(0.0, seed)
+    crnn, pred = _mine(0.0, ocrnn, opred)
+    for m in (ocrnn, opred, crnn, pred):
+        m.train()
+    outs, _ = _stages(ocrnn, x)          # also advances the oracle's running stats once
+    ocrnn, opred = _oracle(0.0, seed)
+    ocrnn.train(); opred.train()
+    loss_ref, out_ref = co.train_losses(ocrnn, opred, x, y)
+    loss_ref.backward()
+
+    enc, ctx = crnn.run_forward(x.cuda(), save=True)
+    rep = _report(ctx, outs)
+    err = float((enc.cpu() - out_ref["enc_syn"].detach()).abs().max())
+    assert err < 1e-4, (err, rep)
+    saved = pred.run_forward(enc)
+    strong, sof, weak, den = saved
+    np.testing.assert_allclose(strong.cpu().numpy(), g["train_strong"], atol=2e-5)
+    np.testing.assert_allclose(weak.cpu().numpy(), g["train_weak"], atol=2e-5)
+    yw = y.max(-2)[0]
+    crnn.zero_grad(); pred.zero_grad()
+    dx, loss_part = pred.run_backward(enc, saved, y_strong=y.cuda(), y_weak=yw.cuda())
+    lp = loss_part.sum(0).cpu().double()
+    loss = float(lp[0] / (B * (T // 4) * 20) + lp[1] / (B * 20))
+    assert abs(loss - float(loss_ref)) < 2e-5 * abs(float(loss_ref)), (loss, float(loss_ref))
+    assert abs(loss - float(g["train_losses"][0])) < 2e-5 * abs(loss)
+    crnn.run_backward(ctx, dx)
+    bad = _grad_check(pred, {k: p.grad for k, p in opred.named_parameters()})
+    assert not bad, bad
+    bad = _grad_check(crnn, {k: p.grad for k, p in ocrnn.named_parameters()})
+    assert not bad, (bad, rep)
+    # running statistics after one training forward
+    for i in range(7):
+        np.testing.assert_allclose(crnn.P(f"cnn.batchnorm{i}.running_var").cpu().numpy(),
+                                   getattr(ocrnn.cnn.cnn, f"batchnorm{i}").running_var.numpy(), rtol=2e-4)
+        assert int(crnn.P(f"cnn.batchnorm{i}.num_batches_tracked")) == 1
+
+
+def test_autograd_dropin_path_matches_fused_path():
+    """reference-style driver: loss from torch ops on (strong, weak), loss.backward(), grads land in .grad"""
+    seed, B, T = 5, 2, 64
+    x = torch.from_numpy(seeded.db_like_input(seed, B, T)).cuda()
+    y = torch.from_numpy(seeded.strong_targets(seed + 1, B, T // 4)).cuda()
+    ocrnn, opred = _oracle(0.0, seed)
+    crnn, pred = _mine(0.0, ocrnn, opred)
+    crnn.train(); pred.train()
+    enc, _ = crnn(x)
+    strong, weak = pred(enc)
+    bce = torch.nn.BCELoss()
+    loss = bce(strong, y) + bce(weak, y.max(-2)[0])
+    crnn.zero_grad(); pred.zero_grad()
+    loss.backward()
+    g_auto = torch.cat([crnn.flat_grad.clone(), pred.flat_grad.clone()])
+    # fused path on a fresh copy (running stats do not matter for gradients)
+    crnn2, pred2 = _mine(0.0, ocrnn, opred)
+    crnn2.train(); pred2.train()
+    enc2, ctx = crnn2.run_forward(x, save=True)
+    saved = pred2.run_forward(enc2)
+    dx, _ = pred2.run_backward(enc2, saved, y_strong=y, y_weak=y.max(-2)[0])
+    crnn2.run_backward(ctx, dx)
+    g_fused = torch.cat([crnn2.flat_grad, pred2.flat_grad])
+    assert float((g_auto - g_fused).norm()) <= 1e-5 * float(g_fused.norm())
+
+
+def test_dropout_is_reproducible_and_unbiased():
+    seed, B, T = 9, 2, 64
+    x = torch.from_numpy(seeded.db_like_input(seed, B, T)).cuda()
+    ocrnn, opred = _oracle(0.5, seed)
+    crnn, _ = _mine(0.5, ocrnn, opred)
+    crnn.train()
+    crnn.set_seed(123)
+    a, _ = crnn.run_forward(x, save=False)
+    b, _ = crnn.run_forward(x, save=False)
+    crnn.set_seed(124)
+    c, _ = crnn.run_forward(x, save=False)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    frac_zero = float((a == 0).float().mean())
+    assert 0.4 < frac_zero < 0.6  # final Dropout(0.5) on the GRU output
+
+
+def test_state_dict_keys_match_reference_layout():
+    from bsed_amd.models import CRNN, Predictor
+    ocrnn, opred = _oracle(0.5, 3)
+    crnn, pred = CRNN(**co.CRNN_KWARGS), Predictor(**co.PREDICTOR_KWARGS)
+    assert set(crnn.state_dict().keys()) == set(ocrnn.state_dict().keys())
+    assert set(pred.state_dict().keys()) == set(opred.state_dict().keys())
+    for k, v in ocrnn.state_dict().items():
+        assert tuple(crnn.state_dict()[k].shape) == tuple(v.shape), k
+    # reference checkpoints are loaded after the "cnn." -> "cnn.cnn." rewrite: accept both spellings
+    sd = {("cnn." + k if k.startswith("cnn.") else k): v for k, v in ocrnn.state_dict().items()}
+    crnn.load_state_dict(sd)
+    np.testing.assert_array_equal(crnn.P("cnn.conv3.weight").detach().cpu().numpy(),
+                                  ocrnn.state_dict()["cnn.conv3.weight"].numpy())

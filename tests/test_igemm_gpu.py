@@ -17,3 +17,115 @@ def test_mfma_fragment_layout():
     L.call("bsed_selftest_mfma", L.ptr(a), L.ptr(b), L.ptr(c), L.c_int(K), L.stream())
     ref = A.astype(np.float64) @ B.astype(np.float64)
     np.testing.assert_allclose(c.cpu().numpy(), ref, atol=1e-4)
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,cin,co", [(2, 13, 64, 16, 32), (1, 37, 32, 32, 64), (2, 21, 16, 64, 128),
+                                          (1, 19, 8, 128, 128), (2, 70, 4, 128, 128), (1, 131, 2, 128, 128),
+                                          (1, 9, 16, 32, 16)])
+def test_conv3x3_forward_stats_and_dgrad(B, H, W, cin, co):
+    from bsed_amd import ops
+    rng = np.random.default_rng(B * 1000 + H)
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((co, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(co).astype(np.float32))
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xg, wg, bg = _nhwc(x).cuda(), w.cuda(), b.cuda()
+    wpk = ops.pack_weight(wg, 9, cin, co, 1, 9, cin * 9)
+    y, stats = ops.igemm(xg, wpk, co, B, H, W, cin, taps=ops.TAPS3x3, bias=bg, epilogue=ops.EPI_STATS)
+    got = y.cpu().double()
+    np.testing.assert_allclose(got.numpy(), _nhwc(ref).numpy(), atol=2e-5)
+    s = stats.double().sum(0).cpu()
+    np.testing.assert_allclose(s[0].numpy(), ref.sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(s[1].numpy(), (ref ** 2).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    # data gradient = conv with flipped taps / swapped channel roles
+    dy = torch.from_numpy(rng.standard_normal((B, co, H, W)).astype(np.float32))
+    dref = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), padding=1)
+    wd = ops.pack_weight(wg, 9, co, cin, 1, cin * 9, 9)
+    dx, _ = ops.igemm(_nhwc(dy).cuda(), wd, cin, B, H, W, co, taps=[(-a, -c) for a, c in ops.TAPS3x3])
+    np.testing.assert_allclose(dx.cpu().double().numpy(), _nhwc(dref).numpy(), atol=5e-5)
+    # weight gradient
+    wref = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=1)
+    part, G, KP, NP = ops.wgrad(xg, _nhwc(dy).cuda(), B, H, W, cin, co, taps=ops.TAPS3x3)
+    dw = torch.zeros_like(wg)
+    ops.reduce_partials(part, G, 9, KP, NP, cin, co, dw, 1, 9, cin * 9)
+    err = float((dw.cpu().double() - wref).norm() / wref.norm())
+    assert err < 1e-5, err
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 128, 768), (129, 256, 768), (1000, 768, 128), (77, 768, 256)])
+def test_plain_gemm_and_tn_wgrad(M, K, N):
+    from bsed_amd import ops
+    rng = np.random.default_rng(M)
+    x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(N).astype(np.float32))
+    xg, wg, bg = x.cuda(), w.cuda(), b.cuda()
+    wpk = ops.pack_weight(wg, 1, K, N, 0, 1, K)
+    y, _ = ops.igemm(xg, wpk, N, 1, M, 1, K, bias=bg)
+    ref = x.double() @ w.double().T + b.double()
+    np.testing.assert_allclose(y.view(M, N).cpu().double().numpy(), ref.numpy(), atol=5e-5)
+    dy = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32))
+    part, G, KP, NP = ops.wgrad(xg, dy.cuda(), 1, M, 1, K, N)
+    dw = torch.zeros_like(wg)
+    ops.reduce_partials(part, G, 1, KP, NP, K, N, dw, 0, 1, K)
+    wref = dy.double().T @ x.double()
+    err = float((dw.cpu().double() - wref).norm() / wref.norm())
+    assert err < 1e-5, err
+
+
+def test_shifted_tap_wgrad_matches_gru_hidden_gradient_form():
+    """dW_hh = sum_t dgh_t^T h_{t-1}: a 1-tap wgrad with a (-1, 0) / (+1, 0) offset and pitched operands"""
+    from bsed_amd import ops
+    rng = np.random.default_rng(3)
+    B, T = 3, 150
+    out = torch.from_numpy(rng.standard_normal((B, T, 256)).astype(np.float32))
+    dgh = torch.from_numpy(rng.standard_normal((B, T, 768)).astype(np.float32))
+    og, dg = out.cuda(), dgh.cuda()
+    for dr in range(2):
+        part, G, KP, NP = ops.wgrad(og, dg, B, T, 1, 128, 384, taps=((-1 if dr == 0 else 1, 0),), in_pitch=256,
+                                    dy_pitch=768, in_offset=dr * 128, dy_offset=dr * 384)
+        dw = torch.zeros((384, 128), device="cuda")
+        ops.reduce_partials(part, G, 1, KP, NP, 128, 384, dw, 0, 1, 128)
+        h = out[:, :, dr * 128:(dr + 1) * 128].double()
+        hp = torch.zeros_like(h)
+        if dr == 0:
+            hp[:, 1:] = h[:, :-1]
+        else:
+            hp[:, :-1] = h[:, 1:]
+        ref = torch.einsum("btj,btk->jk", dgh[:, :, dr * 384:(dr + 1) * 384].double(), hp)
+        err = float((dw.cpu().double() - ref).norm() / ref.norm())
+        assert err < 1e-5, (dr, err)
+
+
+def test_gru_forward_backward_vs_torch():
+    from bsed_amd import ops
+    torch.manual_seed(0)
+    B, T = 3, 40
+    gru = torch.nn.GRU(128, 128, bidirectional=True, batch_first=True)
+    x = torch.randn(B, T, 128)
+    x.requires_grad_()
+    ref, _ = gru(x)
+    dout = torch.randn(B, T, 256)
+    ref.backward(dout)
+    sd = gru.state_dict()
+    w_ih = torch.cat([sd["weight_ih_l0"], sd["weight_ih_l0_reverse"]]).cuda()
+    w_hh = torch.cat([sd["weight_hh_l0"], sd["weight_hh_l0_reverse"]]).contiguous().cuda()
+    b_ih = torch.cat([sd["bias_ih_l0"], sd["bias_ih_l0_reverse"]]).cuda()
+    b_hh = torch.cat([sd["bias_hh_l0"], sd["bias_hh_l0_reverse"]]).cuda()
+    xg = x.detach().cuda()
+    wpk = ops.pack_weight(w_ih, 1, 128, 768, 0, 1, 128)
+    xp, _ = ops.igemm(xg, wpk, 768, 1, B * T, 1, 128, bias=b_ih)
+    out, gates = ops.gru_fwd(xp.view(B, T, 768), w_hh, b_hh, B, T, save_gates=True)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), atol=2e-6)
+    dxp, dgh = ops.gru_bwd(dout.cuda(), out, gates, w_hh, B, T)
+    wd = ops.pack_weight(w_ih, 1, 768, 128, 0, 128, 1)
+    dx, _ = ops.igemm(dxp, wd, 128, 1, B * T, 1, 768)
+    np.testing.assert_allclose(dx.view(B, T, 128).cpu().numpy(), x.grad.numpy(), atol=2e-5)
+    db = torch.zeros(768, device="cuda")
+    ops.colsum(dgh, B * T, 768, 768, db)
+    ref_db = torch.cat([gru.bias_hh_l0.grad, gru.bias_hh_l0_reverse.grad])
+    np.testing.assert_allclose(db.cpu().numpy(), ref_db.numpy(), atol=2e-5)

@@ -56,7 +56,8 @@ def test_db_clamp_pad_and_noisy_view(fe):
             floor = ref[0, :T].max() - 80.0
             live = ref[0, :T] > floor + 1e-3
             assert np.abs(got[0, :T][live] - ref[0, :T][live]).max() < 2e-3
-            assert np.abs(got[0, :T][~live] - ref[0, :T][~live]).max() < 2e-3
+            if (~live).any():
+                assert np.abs(got[0, :T][~live] - ref[0, :T][~live]).max() < 2e-3
             assert got[0, :T].min() >= got[0, :T].max() - 80.0 - 1e-4
 
 
