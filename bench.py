@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 10 s clips/sec through the mel + CRNN train step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N>1)
+
+One "step" = one pass of the hot path over one synthetic batch that is already resident in HBM as raw
+waveforms: STFT/mel/dB on the GPU -> CRNN forward (dropout 0.5, train-mode BatchNorm) -> Predictor ->
+BCE strong + BCE weak -> backward -> (RCCL all-reduce of the flat gradient arenas) -> Adam.  This is
+BASELINE.json configs[2] ("main_baseline.py full CRNN train step on SYN, batch 256 per GPU"), the
+configuration the metric is quoted on; data parallel = weak scaling (256 clips per GPU).
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant MFMA kernel, HIP-event timed inside the timed
+region) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_waves(B, n, sr, seed, device):
+    """Deterministic synthetic clips (SURVEY.md 8d recipe, generated on the GPU): 0.1*N(0,1) floor plus three
+    tones/chirps per clip with random onset/offset; returns (wave (B,n), events[(on,off,cls)] per clip)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    t = torch.arange(n, device=device, dtype=torch.float32) / sr
+    y = 0.1 * torch.randn((B, n), generator=torch.Generator(device=device).manual_seed(seed), device=device)
+    dur = n / sr
+    ev = []
+    par = torch.rand((B, 3, 6), generator=g)
+    for b in range(B):
+        evb = []
+        for e in range(3):
+            f0 = 500 + float(par[b, e, 0]) * (sr / 2 - 1000)
+            f1 = 500 + float(par[b, e, 1]) * (sr / 2 - 1000) if float(par[b, e, 2]) < 0.5 else f0
+            amp = 0.05 + 0.45 * float(par[b, e, 3])
+            on = float(par[b, e, 4]) * (dur - 0.2)
+            off = on + 0.2 + float(par[b, e, 5]) * (dur - on - 0.2)
+            i0, i1 = int(on * sr), min(n, int(off * sr))
+            tt = t[i0:i1] - on
+            y[b, i0:i1] += amp * torch.sin(2 * np.pi * (f0 * tt + 0.5 * (f1 - f0) * tt * tt / (off - on)))
+            evb.append((on, off, int(par[b, e, 2] * 1e6) % 20))
+        ev.append(evb)
+    return y.clamp_(-1, 1), ev
+
+
+def strong_labels(events, Tp, sr, hop, pooling, device):
+    """frame index = int(t * sr // hop // pooling)  (reference ManyHotEncoder.py:121-122)"""
+    y = torch.zeros((len(events), Tp, 20), dtype=torch.float32)
+    for b, evb in enumerate(events):
+        for on, off, c in evb:
+            y[b, int(on * sr // hop // pooling):int(off * sr // hop // pooling), c] = 1
+    return y.to(device)
+
+
+def cpu_baseline(sr, seconds, threads):
+    """The CPU oracle (numpy mel restatement + stock torch.nn CRNN train step) on this host's cores."""
+    from oracle import crnn_oracle as co
+    from oracle import mel_oracle as mo
+    torch.set_num_threads(threads)
+    n_mel = 4
+    clips = [mo.synth_clip(i, sr=sr, seconds=seconds)[0] for i in range(n_mel)]
+    t0 = time.perf_counter()
+    mels = [mo.transform_pair(mo.preprocess(c, sr=sr, fmax=min(16000.0, sr / 2)), 1 + len(c) // 255,
+                              unit_noise=np.zeros((1 + len(c) // 255, 128)))[0] for c in clips]
+    t_mel = (time.perf_counter() - t0) / n_mel
+    B = 8
+    crnn, pred = co.build(seed=1, dropout=0.5)
+    crnn.train(); pred.train()
+    opt = torch.optim.Adam(list(crnn.parameters()) + list(pred.parameters()), lr=1e-3)
+    x = torch.from_numpy(np.stack([mels[i % n_mel] for i in range(B)]))
+    Tp = x.shape[2] // 4
+    y = torch.zeros((B, Tp, 20)); y[:, Tp // 3: Tp // 2, 3] = 1
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss, _ = co.train_losses(crnn, pred, x, y)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t_step = float(np.mean(times[1:])) / B
+    return {"value": 1.0 / (t_mel + t_step), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"numpy mel on {n_mel} clips (single thread, {t_mel*1e3:.0f} ms/clip) + torch CPU CRNN train "
+                      f"step B={B}, 1 warm-up + 2 timed ({t_step*1e3:.0f} ms/clip), {seconds:g} s clips @ {sr} Hz"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--sr", type=int, default=22050, help="22050 = BASELINE measurement config, 32000 = reference config")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    t_start = time.perf_counter()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    from bsed_amd import ops
+    from bsed_amd.engine import FlatAdam, SEDTrainer
+    from bsed_amd.features import MelConfig, MelFrontEnd
+    from bsed_amd.models import CRNN, Predictor, weights_init
+
+    kw = dict(n_in_channel=1, nclass=20, attention=True, n_RNN_cell=128, n_layers_RNN=2, activation="glu",
+              dropout=0.5, kernel_size=7 * [3], padding=7 * [1], stride=7 * [1],
+              nb_filters=[16, 32, 64, 128, 128, 128, 128],
+              pooling=[[2, 2], [2, 2], [1, 2], [1, 2], [1, 2], [1, 2], [1, 2]])
+    torch.manual_seed(2023)
+    crnn, pred = CRNN(**kw), Predictor(nclass=20, attention=True, n_RNN_cell=128)
+    weights_init(crnn); weights_init(pred)
+    mcfg = MelConfig(sr=args.sr)
+    fe = MelFrontEnd(mcfg)
+    tr = SEDTrainer(crnn, pred, optimizer=FlatAdam([crnn, pred], lr=1e-3), frontend=fe, seed=2023)
+    tr.broadcast_parameters()
+
+    B, n = args.batch, int(args.seconds * args.sr)
+    wav, ev = synth_waves(B, n, args.sr, 2023 + rank, dev)
+    T = fe.num_frames(n)
+    Tp = T // 4
+    y = strong_labels(ev, Tp, args.sr, mcfg.hop_size, 4, dev)
+
+    def step():
+        return tr.train_step(wav, y, from_wave=True)
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    log(f"data ready: B={B} n={n} T={T} Tp={Tp}")
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done")
+    timer = None
+    if not args.no_kernel_timer and rank == 0:
+        timer = ops.KernelTimer()
+        ops.set_timer(timer)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.set_timer(None)
+    log(f"timed region done: {elapsed:.3f}s for {args.steps} steps")
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax)
+    loss = SEDTrainer.loss_value(out)
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    value = world * B * args.steps / elapsed
+    roofline = None
+    kernels = {}
+    if timer is not None:
+        summ = timer.summary()
+        tot_ms = sum(v[1] for v in summ.values())
+        key = max(summ, key=lambda k: summ[k][1])
+        launches, total_ms, avg_ms, flops = summ[key]
+        achieved = flops / (avg_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": "%s epi=%d taps=%d CIN=%d N=%d HxW=%dx%d" % key,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                    "algorithmic_gflop_per_launch": round(flops / 1e9, 3),
+                    "share_of_mfma_kernel_time": round(total_ms / tot_ms, 3),
+                    "mfma_kernels_ms_per_step": round(tot_ms / args.steps, 3)}
+        for k in sorted(summ, key=lambda k: -summ[k][1]):
+            c, tms, ams, fl = summ[k]
+            log("  %-46s x%-3d %8.3f ms/step  avg %7.3f ms  %6.1f TFLOP/s" % (
+                "%s e%d t%d CIN%d N%d %dx%d" % k, c // args.steps, tms / args.steps, ams, fl / ams / 1e9))
+        all_flops = sum(v[0] * v[3] for v in summ.values())
+        kernels = {"all_mfma_kernels_tflops": round(all_flops / (tot_ms * 1e-3) / 1e12, 2)}
+    cpu = None
+    if not args.no_cpu_baseline:
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncpu = os.cpu_count() or 1
+        cpu = cpu_baseline(args.sr, args.seconds, max(1, min(ncpu, 16)))
+        log("cpu baseline done")
+    line = {
+        "metric": "10 s clips/sec through mel+CRNN train step", "value": round(value, 2), "unit": "clips/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "waveform->STFT/mel/dB->CRNN(7 conv/BN/GLU/pool + 2xBiGRU128)->Predictor->BCE strong+weak"
+                               "->backward->Adam; BASELINE configs[2] (main_baseline.py train step on SYN)",
+                   "clip_seconds": args.seconds, "sr": args.sr, "frames": T, "out_frames": Tp,
+                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "dropout": 0.5},
+        "roofline": roofline, "cpu_baseline": cpu, "final_loss": round(loss, 5),
+    }
+    line.update(kernels)
+    print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

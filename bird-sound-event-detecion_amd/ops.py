@@ -42,6 +42,45 @@ class HeadBwdDesc(ctypes.Structure):
 TAPS3x3 = [(kh - 1, kw - 1) for kh in range(3) for kw in range(3)]
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing of the MFMA kernels (bench.py's roofline leg).  Events are
+    recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = {}  # key -> [flops_per_launch, [(start, end), ...]]
+
+    def launch(self, key, flops, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        rec = self.records.setdefault(key, [flops, []])
+        rec[1].append((s, e))
+
+    def summary(self):
+        """{key: (launches, total_ms, avg_ms, flops_per_launch)} -- call after a device sync"""
+        out = {}
+        for key, (flops, evs) in self.records.items():
+            ms = [s.elapsed_time(e) for s, e in evs]
+            out[key] = (len(ms), float(sum(ms)), float(sum(ms) / len(ms)), flops)
+        return out
+
+
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t
+
+
+def _launch(key, flops, fn):
+    if _timer is None:
+        fn()
+    else:
+        _timer.launch(key, flops, fn)
+
+
 def round_up(v, m):
     return (v + m - 1) // m * m
 
@@ -100,7 +139,8 @@ def igemm(inp, wpk, N, NB, H, W, CIN, taps=((0, 0),), bias=None, out=None, epilo
     d.ph, d.pw, d.Hp, d.Wp = ph, pw, Hp, Wp
     d.epilogue = epilogue
     d.drop_p, d.rng_stream, d.seed = drop_p, rng_stream, seed
-    L.call("bsed_igemm", ctypes.byref(d), L.stream())
+    _launch(("igemm", epilogue, len(taps), CIN, N, H, W), 2.0 * NB * H * W * len(taps) * CIN * N,
+            lambda: L.call("bsed_igemm", ctypes.byref(d), L.stream()))
     return out, stats
 
 
@@ -123,7 +163,8 @@ def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=Non
     d.ntaps = len(taps)
     for i, (a, b) in enumerate(taps):
         d.dh[i], d.dw[i] = a, b
-    L.call("bsed_wgrad", ctypes.byref(d), L.stream())
+    _launch(("wgrad", 0, len(taps), CIN, N, H, W), 2.0 * NB * H * W * len(taps) * CIN * N,
+            lambda: L.call("bsed_wgrad", ctypes.byref(d), L.stream()))
     return part, G, CINP, NP
 
 
