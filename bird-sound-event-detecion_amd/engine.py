@@ -19,6 +19,7 @@ import torch
 
 from . import _lib as L
 from . import ops
+from . import parallel
 
 
 # ----------------------------------------------------------------------------- schedules
@@ -153,22 +154,18 @@ class SEDTrainer:
         for m in (self.crnn, self.predictor, self.ema_crnn, self.ema_predictor):
             if m is None:
                 continue
-            torch.distributed.broadcast(m.flat, src, group=self.pg)
-            if getattr(m, "flat_buf", None) is not None:
-                torch.distributed.broadcast(m.flat_buf, src, group=self.pg)
+            bufs = [m.flat] + ([m.flat_buf] if getattr(m, "flat_buf", None) is not None else [])
+            parallel.broadcast_flat(bufs, src, self.pg)
 
     def _features(self, wav, noisy=False):
         T = self.frontend.num_frames(wav.shape[1])
         return self.frontend.transform(wav, max_frames=T, noisy=noisy,
-                                       seed=self.seed * 1000003 + self.global_step * 64 + self.rank)
+                                       seed=parallel.rank_seed(self.seed, self.global_step, self.rank))
 
     def _all_reduce_grads(self):
         if self.world == 1:
             return
-        works = [torch.distributed.all_reduce(m.flat_grad, group=self.pg, async_op=True)
-                 for m in (self.crnn, self.predictor)]
-        for w in works:
-            w.wait()
+        parallel.all_reduce_flat([self.crnn.flat_grad, self.predictor.flat_grad], self.pg)
 
     def train_step(self, syn_x, syn_y, real_x=None, real_y_weak=None, real_x_ema=None, consistency_cost=None,
                    from_wave=False):
@@ -187,7 +184,7 @@ class SEDTrainer:
                     real_x, real_x_ema = self._features(real_x, noisy=True)
                 else:
                     real_x = self._features(real_x)
-        step_seed = self.seed * 1000003 + self.global_step * 64 + self.rank
+        step_seed = parallel.rank_seed(self.seed, self.global_step, self.rank)
         crnn.train(); pred.train()
         self.optimizer.zero_grad()
         out = {}

@@ -1,0 +1,70 @@
+"""N>1 logic on CPU: world_size-2 gloo processes exercise the same helpers the GPU trainer uses
+(bsed_amd.parallel): strided clip sharding, flat-buffer sum all-reduce with the 1/world factor applied by the
+optimizer, parameter broadcast, per-rank seeds, max-over-ranks timing."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bsed_amd import parallel
+    torch.manual_seed(0)
+    # a tiny model whose parameters live in one flat arena, like the real modules
+    flat = torch.randn(37)
+    if rank != 0:
+        flat.add_(1.0)  # deliberately different before the broadcast
+    parallel.broadcast_flat([flat])
+    W = flat[:30].view(3, 10)
+    b = flat[30:33]
+    X = torch.arange(8 * 10, dtype=torch.float32).view(8, 10) / 80.0
+    Y = torch.arange(8 * 3, dtype=torch.float32).view(8, 3) / 24.0
+    xs, ys = parallel.shard_batch(X, rank, world), parallel.shard_batch(Y, rank, world)
+    # per-rank gradient of the per-rank MEAN loss, summed over ranks, scaled by 1/world == full-batch gradient
+    W_ = W.clone().requires_grad_(); b_ = b.clone().requires_grad_()
+    ((xs @ W_.T + b_ - ys) ** 2).mean().backward()
+    g = torch.cat([W_.grad.flatten(), b_.grad, torch.zeros(4)])
+    parallel.all_reduce_flat([g])
+    g_dp = g / world
+    Wf = W.clone().requires_grad_(); bf = b.clone().requires_grad_()
+    ((X @ Wf.T + bf - Y) ** 2).mean().backward()
+    g_full = torch.cat([Wf.grad.flatten(), bf.grad, torch.zeros(4)])
+    tmax = parallel.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    q.put((rank, flat.numpy().copy(), float((g_dp - g_full).abs().max()), tmax,
+           parallel.shard_indices(7, rank, world), parallel.rank_seed(2023, 5, rank)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, flat0, e0, t0, idx0, s0), (r1, flat1, e1, t1, idx1, s1) = res
+    np.testing.assert_array_equal(flat0, flat1)           # broadcast made the replicas identical
+    assert e0 < 1e-6 and e1 < 1e-6                        # sum-all-reduce * 1/world == full-batch gradient
+    assert t0 == t1 == 2.0                                # max over ranks
+    assert idx0 == [0, 2, 4, 6] and idx1 == [1, 3, 5]     # clips r::world
+    assert s0 != s1                                       # per-rank Philox seeds
+
+
+def test_single_process_helpers_are_noops():
+    from bsed_amd import parallel
+    g = torch.ones(5)
+    assert parallel.all_reduce_flat([g]) == [] and torch.equal(g, torch.ones(5))
+    parallel.broadcast_flat([g])
+    assert parallel.max_over_ranks(3.5, torch.device("cpu")) == 3.5
