@@ -279,8 +279,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
 // elementwise dropout: out = in * keep/(1-p)   (forward and backward use the same call)
 __global__ void dropout_kernel(const float* __restrict__ in, float* __restrict__ out, long n, float p,
                                uint32_t rng_stream, uint64_t seed) {
+  const uint32_t key = drop_key(rng_stream, seed), thr = drop_threshold(p);
+  const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    out[i] = in[i] * dropout_scale((uint64_t)i, rng_stream, seed, p);
+    out[i] = in[i] * drop_mul((uint64_t)i, key, thr, sc);
 }
 
 // ---------------------------------------------------------------------------------------------

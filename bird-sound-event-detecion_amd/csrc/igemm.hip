@@ -26,7 +26,7 @@ enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_GLU_POOL = 2, EPI_GLU_BWD = 3, EPI_ADD_
 
 struct IgemmParams {
   BsedIgemmDesc d;
-  int PW, PH, PP, lgTW, b_off;  // derived on the host
+  int PW, PH, PP, lgTW, b_off, pw_magic;  // derived on the host; pos / PW == (pos * pw_magic) >> 20
 };
 
 __device__ __forceinline__ int crow(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
@@ -59,22 +59,36 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_kernel(const IgemmParams P) 
   const float* inb = p.in + (size_t)nb * p.H * p.W * p.in_pitch;
   for (int c0 = 0; c0 < p.CIN; c0 += KC) {
     __syncthreads();
-    for (int e = tid; e < P.PP * (KC / 4); e += IG_THREADS) {
-      const int c4 = e % (KC / 4), pos = e / (KC / 4);
-      const int pr = pos / PW, pc = pos - pr * PW;
-      const int gh = th0 - p.hh + pr, gw = tw0 - p.hw + pc;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) {
-        v = *reinterpret_cast<const float4*>(inb + ((size_t)gh * p.W + gw) * p.in_pitch + c0 + 4 * c4);
-        if (p.a_scale) {
-          const float4 sc = *reinterpret_cast<const float4*>(p.a_scale + c0 + 4 * c4);
-          const float4 sh = *reinterpret_cast<const float4*>(p.a_shift + c0 + 4 * c4);
-          v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-          v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+    // global loads are issued four at a time before any LDS store so their latencies overlap
+    const int a_total = P.PP * (KC / 4);
+    for (int e0 = tid; e0 < a_total; e0 += 4 * IG_THREADS) {
+      float4 v[4];
+      bool okv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * IG_THREADS;
+        const int c4 = e % (KC / 4), pos = e / (KC / 4);
+        const int pr = (pos * P.pw_magic) >> 20, pc = pos - pr * PW;
+        const int gh = th0 - p.hh + pr, gw = tw0 - p.hw + pc;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        okv[u] = e < a_total && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+        if (okv[u]) v[u] = *reinterpret_cast<const float4*>(inb + ((size_t)gh * p.W + gw) * p.in_pitch + c0 + 4 * c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * IG_THREADS;
+        if (e < a_total) {
+          const int c4 = e % (KC / 4), pos = e / (KC / 4);
+          if (p.a_scale && okv[u]) {
+            const float4 sc = *reinterpret_cast<const float4*>(p.a_scale + c0 + 4 * c4);
+            const float4 sh = *reinterpret_cast<const float4*>(p.a_shift + c0 + 4 * c4);
+            v[u].x = fmaf(v[u].x, sc.x, sh.x); v[u].y = fmaf(v[u].y, sc.y, sh.y);
+            v[u].z = fmaf(v[u].z, sc.z, sh.z); v[u].w = fmaf(v[u].w, sc.w, sh.w);
+          }
+          float* dst = As + pos * AP + 4 * c4;
+          dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
         }
       }
-      float* dst = As + pos * AP + 4 * c4;
-      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     }
     for (int tap = 0; tap < p.ntaps; ++tap) {
       if (tap > 0) __syncthreads();
@@ -100,64 +114,83 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_kernel(const IgemmParams P) 
   }
 
   // ------------------------------------------------------------------------------------ epilogue
+  // VALU-lean by construction: position math once per accumulator register (not per channel tile),
+  // pooling windows are 1 or 2 (shifts, no integer division), dropout from a 32-bit mix hash.
   float s0[NT], s1[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
-  if (EPI == EPI_GLU_POOL) __syncthreads();  // As/Bs are recycled as the pooling stage
-  float* Cs = smem;                          // [128][BN+1]
-
+  float bias[NT], esc[NT], esh[NT];
+  bool nok[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
+    s0[j] = 0.f; s1[j] = 0.f;
     const int n = n0 + 32 * j + li;
-    const bool nok = n < p.N;
-    const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
-    float esc = 0.f, esh = 0.f;
+    nok[j] = n < p.N;
+    bias[j] = (p.bias && nok[j]) ? p.bias[n] : 0.f;
+    esc[j] = 0.f; esh[j] = 0.f;
     if (EPI == EPI_GLU_POOL || EPI == EPI_GLU_BWD) {
-      if (nok) { esc = p.e_scale[n]; esh = p.e_shift[n]; }
+      if (nok[j]) { esc[j] = p.e_scale[n]; esh[j] = p.e_shift[n]; }
+    }
+  }
+  if (EPI == EPI_GLU_POOL) __syncthreads();  // As/Bs are recycled as the pooling stage
+  float* Cs = smem;                          // [128][BN+1]
+  const int sph = p.ph >> 1, spw = p.pw >> 1;  // pooling windows are 1 or 2
+  const float inv_pool = 1.0f / (float)(p.ph * p.pw);
+  const uint32_t dkey = drop_key(p.rng_stream, p.seed);
+  const uint32_t dthr = drop_threshold(p.drop_p);
+  const float dscale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  const int nbase = n0 + li;
+
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int mm = wave * 32 + crow(r, lh);
+    const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
+    const bool pok = gh < p.H && gw < p.W;
+    const size_t pos = ((size_t)nb * p.H + gh) * p.W + gw;
+    float* orow = p.out + pos * p.out_pitch + nbase;
+    const float* erow = p.e_src + pos * p.e_pitch + nbase;
+    const uint64_t ebase = (uint64_t)pos * p.N + nbase;
+    const float* dprow = nullptr;
+    bool pooled_ok = false;
+    if (EPI == EPI_GLU_BWD) {
+      const int gph = gh >> sph, gpw = gw >> spw;
+      pooled_ok = pok && gph < p.Hp && gpw < p.Wp;
+      dprow = p.e_dpool + (((size_t)nb * p.Hp + gph) * p.Wp + gpw) * p.N + nbase;
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int mm = wave * 32 + crow(r, lh);
-      const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
-      const bool ok = nok && gh < p.H && gw < p.W;
-      const size_t pos = ((size_t)nb * p.H + gh) * p.W + gw;
-      float v = acc[j][r] + bias;
+    for (int j = 0; j < NT; ++j) {
+      const bool ok = pok && nok[j];
+      const float v = acc[j][r] + bias[j];
       if (EPI == EPI_PLAIN) {
-        if (ok) p.out[pos * p.out_pitch + n] = v;
+        if (ok) orow[32 * j] = v;
       } else if (EPI == EPI_STATS) {
         if (ok) {
-          p.out[pos * p.out_pitch + n] = v;
+          orow[32 * j] = v;
           s0[j] += v;
           s1[j] = fmaf(v, v, s1[j]);
         }
       } else if (EPI == EPI_GLU_POOL) {
         float res = 0.f;
         if (ok) {
-          const float xn = fmaf(p.e_src[pos * p.e_pitch + n], esc, esh);
-          res = v * sigmoidf_(xn) * dropout_scale(pos * p.N + n, p.rng_stream, p.seed, p.drop_p);
+          const float xn = fmaf(erow[32 * j], esc[j], esh[j]);
+          res = v * sigmoid_fast(xn) * drop_mul(ebase + 32 * j, dkey, dthr, dscale);
         }
         Cs[mm * (BN + 1) + 32 * j + li] = res;
       } else if (EPI == EPI_GLU_BWD) {
         if (ok) {
-          const float xn = fmaf(p.e_src[pos * p.e_pitch + n], esc, esh);
-          const float sg = sigmoidf_(xn);
+          const float xn = fmaf(erow[32 * j], esc[j], esh[j]);
+          const float sg = sigmoid_fast(xn);
           float dres = 0.f;
-          const int gph = gh / p.ph, gpw = gw / p.pw;
-          if (gph < p.Hp && gpw < p.Wp) {
-            dres = p.e_dpool[(((size_t)nb * p.Hp + gph) * p.Wp + gpw) * p.N + n] * (1.0f / (float)(p.ph * p.pw)) *
-                   dropout_scale(pos * p.N + n, p.rng_stream, p.seed, p.drop_p);
-          }
+          if (pooled_ok) dres = dprow[32 * j] * inv_pool * drop_mul(ebase + 32 * j, dkey, dthr, dscale);
           const float dlin = dres * sg;
-          p.out[pos * p.out_pitch + n] = dlin;
-          p.out2[pos * p.out_pitch + n] = dres * v * sg * (1.0f - sg);
+          orow[32 * j] = dlin;
+          p.out2[pos * p.out_pitch + nbase + 32 * j] = dres * v * sg * (1.0f - sg);
           s0[j] += dlin;
         }
       } else {  // EPI_ADD_STATS2: g = acc + residual ; stats = (sum g, sum g*y)
         if (ok) {
-          const float g = v + p.out2[pos * p.out_pitch + n];
-          p.out[pos * p.out_pitch + n] = g;
+          const float g = v + p.out2[pos * p.out_pitch + nbase + 32 * j];
+          orow[32 * j] = g;
           s0[j] += g;
-          s1[j] = fmaf(g, p.e_src[pos * p.e_pitch + n], s1[j]);
+          s1[j] = fmaf(g, erow[32 * j], s1[j]);
         }
       }
     }
@@ -165,18 +198,21 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_kernel(const IgemmParams P) 
 
   if (EPI == EPI_GLU_POOL) {
     __syncthreads();
-    const int tpw = p.TW / p.pw, tph = p.TH / p.ph;
-    const float inv = 1.0f / (float)(p.ph * p.pw);
+    const int lgtpw = P.lgTW - spw;
+    const int tpw = 1 << lgtpw, tph = p.TH >> sph;
     for (int e = tid; e < tph * tpw * BN; e += IG_THREADS) {
       const int n = e % BN, pp = e / BN;
-      const int pr = pp / tpw, pc = pp - pr * tpw;
-      const int gph = th0 / p.ph + pr, gpw = tw0 / p.pw + pc;
+      const int pr = pp >> lgtpw, pc = pp & (tpw - 1);
+      const int gph = (th0 >> sph) + pr, gpw = (tw0 >> spw) + pc;
       if (gph < p.Hp && gpw < p.Wp && n0 + n < p.N) {
-        float s = 0.f;
-        for (int i = 0; i < p.ph; ++i)
-          for (int jj = 0; jj < p.pw; ++jj)
-            s += Cs[((pr * p.ph + i) * p.TW + pc * p.pw + jj) * (BN + 1) + n];
-        p.out[(((size_t)nb * p.Hp + gph) * p.Wp + gpw) * p.out_pitch + n0 + n] = s * inv;
+        const float* c0 = Cs + (((pr << sph) << P.lgTW) + (pc << spw)) * (BN + 1) + n;
+        float s = c0[0];
+        if (spw) s += c0[BN + 1];
+        if (sph) {
+          s += c0[p.TW * (BN + 1)];
+          if (spw) s += c0[(p.TW + 1) * (BN + 1)];
+        }
+        p.out[(((size_t)nb * p.Hp + gph) * p.Wp + gpw) * p.out_pitch + n0 + n] = s * inv_pool;
       }
     }
   }
@@ -210,30 +246,36 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_kernel(const IgemmParams P) 
 // ---------------------------------------------------------------------------------------------
 struct WgradParams {
   BsedWgradDesc d;
-  int PW, PH, PP, lgTW, dy_off, ntiles, nct;  // nct = CINP/32
+  int PW, PH, PP, lgTW, dy_off, ntiles, nct, ntw;  // nct = CC/32, ntw = 32-wide dy tiles per workgroup
+  int CC, lgc4, pw_magic;                          // input-channel chunk per workgroup (grid.z), log2(CC/4)
 };
 
 template <int MAXS>
 __global__ __launch_bounds__(IG_THREADS) void wgrad_kernel(const WgradParams P) {
   const BsedWgradDesc& p = P.d;
   extern __shared__ __align__(16) float smem[];
-  const int XP = p.CINP + 1;
+  const int XP = P.CC + 1;
+  const int cz0 = blockIdx.z * P.CC;
   float* Xs = smem;
-  float* DYs = smem + P.dy_off;  // [128][32]
+  float* DYs = smem + P.dy_off;  // [128][32*ntw]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  const int n0 = blockIdx.y * 32;
+  const int DYW = 32 * P.ntw;
+  const int n0 = blockIdx.y * DYW;
   const int PW = P.PW;
-  const int nitems = p.ntaps * P.nct;
+  const int nitems = p.ntaps * P.nct * P.ntw;
 
-  int xoff[MAXS];
+  int xoff[MAXS], boff[MAXS];
   bool valid[MAXS];
   f32x16 acc[MAXS];
 #pragma unroll
   for (int s = 0; s < MAXS; ++s) {
     const int it = wave + 4 * s;
     valid[s] = it < nitems;
-    const int tap = valid[s] ? it / P.nct : 0, cit = valid[s] ? it % P.nct : 0;
+    // item -> (input-channel tile, dy tile, tap); a wave's items share the channel tile when ntw == 4
+    const int cit = valid[s] ? it % P.nct : 0, rr = valid[s] ? it / P.nct : 0;
+    const int nt = rr % P.ntw, tap = rr / P.ntw;
     xoff[s] = (p.dh[tap] * PW + p.dw[tap]) * XP + cit * 32 + li;
+    boff[s] = nt * 32 + li;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
   }
@@ -247,57 +289,86 @@ __global__ __launch_bounds__(IG_THREADS) void wgrad_kernel(const WgradParams P) 
     const float* inb = p.in + (size_t)nb * p.H * p.W * p.in_pitch;
     const float* dyb = p.dy + (size_t)nb * p.H * p.W * p.dy_pitch;
     __syncthreads();
-    const int c4n = p.CINP / 4;
-    for (int e = tid; e < P.PP * c4n; e += IG_THREADS) {
-      const int c4 = e % c4n, pos = e / c4n;
-      const int pr = pos / PW, pc = pos - pr * PW;
-      const int gh = th0 - p.hh + pr, gw = tw0 - p.hw + pc;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gh >= 0 && gh < p.H && gw >= 0 && gw < p.W && 4 * c4 < p.CIN) {
-        v = *reinterpret_cast<const float4*>(inb + ((size_t)gh * p.W + gw) * p.in_pitch + 4 * c4);
-        if (p.a_scale) {
-          const float4 sc = *reinterpret_cast<const float4*>(p.a_scale + 4 * c4);
-          const float4 sh = *reinterpret_cast<const float4*>(p.a_shift + 4 * c4);
-          v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-          v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+    const int c4n = 1 << P.lgc4;
+    const int x_total = P.PP * c4n;
+    for (int e0 = tid; e0 < x_total; e0 += 4 * IG_THREADS) {
+      float4 v[4];
+      bool okv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * IG_THREADS;
+        const int c4 = e & (c4n - 1), pos = e >> P.lgc4;
+        const int pr = (pos * P.pw_magic) >> 20, pc = pos - pr * PW;
+        const int gh = th0 - p.hh + pr, gw = tw0 - p.hw + pc;
+        const int cg = cz0 + 4 * c4;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        okv[u] = e < x_total && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W && cg < p.CIN;
+        if (okv[u]) v[u] = *reinterpret_cast<const float4*>(inb + ((size_t)gh * p.W + gw) * p.in_pitch + cg);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * IG_THREADS;
+        if (e < x_total) {
+          const int c4 = e & (c4n - 1), pos = e >> P.lgc4;
+          if (p.a_scale && okv[u]) {
+            const int cg = cz0 + 4 * c4;
+            const float4 sc = *reinterpret_cast<const float4*>(p.a_scale + cg);
+            const float4 sh = *reinterpret_cast<const float4*>(p.a_shift + cg);
+            v[u].x = fmaf(v[u].x, sc.x, sh.x); v[u].y = fmaf(v[u].y, sc.y, sh.y);
+            v[u].z = fmaf(v[u].z, sc.z, sh.z); v[u].w = fmaf(v[u].w, sc.w, sh.w);
+          }
+          float* dst = Xs + pos * XP + 4 * c4;
+          dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
         }
       }
-      float* dst = Xs + pos * XP + 4 * c4;
-      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     }
-    for (int e = tid; e < IG_TILE_M * 8; e += IG_THREADS) {
-      const int n4 = e & 7, mm = e >> 3;
-      const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gh < p.H && gw < p.W && n0 + 4 * n4 < p.N)
-        v = *reinterpret_cast<const float4*>(dyb + ((size_t)gh * p.W + gw) * p.dy_pitch + n0 + 4 * n4);
-      *reinterpret_cast<float4*>(DYs + mm * 32 + 4 * n4) = v;
+    const int n4n = 8 * P.ntw;
+    const int lgn4 = P.ntw == 4 ? 5 : (P.ntw == 2 ? 4 : 3);
+    for (int e0 = tid; e0 < IG_TILE_M * n4n; e0 += 4 * IG_THREADS) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * IG_THREADS;  // IG_TILE_M * n4n is a multiple of 4 * IG_THREADS
+        const int n4 = e & (n4n - 1), mm = e >> lgn4;
+        const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gh < p.H && gw < p.W && n0 + 4 * n4 < p.N)
+          v[u] = *reinterpret_cast<const float4*>(dyb + ((size_t)gh * p.W + gw) * p.dy_pitch + n0 + 4 * n4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * IG_THREADS;
+        const int n4 = e & (n4n - 1), mm = e >> lgn4;
+        *reinterpret_cast<float4*>(DYs + mm * DYW + 4 * n4) = v[u];
+      }
     }
     __syncthreads();
 #pragma unroll 2
     for (int kp = 0; kp < IG_TILE_M; kp += 2) {
       const int mk = kp + lh;
-      const float b = DYs[mk * 32 + li];
+      const float* dyrow = DYs + mk * DYW;
       const float* xrow = Xs + (((mk >> P.lgTW) + p.hh) * PW + (mk & (p.TW - 1)) + p.hw) * XP;
 #pragma unroll
       for (int s = 0; s < MAXS; ++s) {
         if (valid[s]) {
           const float a = xrow[xoff[s]];
+          const float b = dyrow[boff[s]];
           acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[s], 0, 0, 0);
         }
       }
     }
   }
-  const int NPo = gridDim.y * 32;
+  const int NPo = gridDim.y * DYW;
 #pragma unroll
   for (int s = 0; s < MAXS; ++s) {
     if (valid[s]) {
       const int it = wave + 4 * s;
-      const int tap = it / P.nct, cit = it % P.nct;
+      const int cit = it % P.nct, rr = it / P.nct;
+      const int nt = rr % P.ntw, tap = rr / P.ntw;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int ci = cit * 32 + crow(r, lh);
-        p.part[(((size_t)blockIdx.x * p.ntaps + tap) * p.CINP + ci) * NPo + n0 + li] = acc[s][r];
+        const int ci = cz0 + cit * 32 + crow(r, lh);
+        p.part[(((size_t)blockIdx.x * p.ntaps + tap) * p.CINP + ci) * NPo + n0 + nt * 32 + li] = acc[s][r];
       }
     }
   }
@@ -313,8 +384,16 @@ __global__ void reduce_partials_kernel(const float* __restrict__ part, int G, in
     const long r = e / NP;
     const int k = (int)(r % KP), tap = (int)(r / KP);
     if (n >= N || k >= K) continue;
-    float s = 0.f;
-    for (int g = 0; g < G; ++g) s += part[(size_t)g * total + e];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = 0;
+    for (; g + 4 <= G; g += 4) {
+      s0 += part[(size_t)g * total + e];
+      s1 += part[(size_t)(g + 1) * total + e];
+      s2 += part[(size_t)(g + 2) * total + e];
+      s3 += part[(size_t)(g + 3) * total + e];
+    }
+    for (; g < G; ++g) s0 += part[(size_t)g * total + e];
+    const float s = (s0 + s1) + (s2 + s3);
     float* d = dst + tap * s_tap + k * s_k + n * s_n;
     *d = accumulate ? *d + s : s;
   }
@@ -399,16 +478,21 @@ extern "C" int bsed_igemm(const BsedIgemmDesc* desc, void* stream) {
   P.PH = d.TH + 2 * d.hh;
   P.PP = P.PW * P.PH;
   P.b_off = (P.PP * (KC + 1) + 3) & ~3;
+  P.pw_magic = ((1 << 20) + P.PW - 1) / P.PW;
+  for (int pos = 0; pos < P.PP; ++pos)
+    BSED_CHECK_ARG(((pos * P.pw_magic) >> 20) == pos / P.PW, "bsed_igemm: internal: magic division fails for PW=%d", P.PW);
   size_t fl = (size_t)P.b_off + (size_t)KC * BN;
   if (d.epilogue == EPI_GLU_POOL) {
-    BSED_CHECK_ARG(d.ph >= 1 && d.pw >= 1 && d.TH % d.ph == 0 && d.TW % d.pw == 0, "bsed_igemm: tile not pool aligned");
+    BSED_CHECK_ARG((d.ph == 1 || d.ph == 2) && (d.pw == 1 || d.pw == 2) && d.TH % d.ph == 0 && d.TW % d.pw == 0,
+                   "bsed_igemm: pooling windows must be 1 or 2 and divide the tile");
     BSED_CHECK_ARG(d.Hp == d.H / d.ph && d.Wp == d.W / d.pw, "bsed_igemm: bad pooled shape");
     fl = std::max(fl, (size_t)IG_TILE_M * (BN + 1));
   }
   if (d.epilogue == EPI_GLU_POOL || d.epilogue == EPI_GLU_BWD)
     BSED_CHECK_ARG(d.e_src && d.e_scale && d.e_shift && d.e_pitch >= d.N, "bsed_igemm: GLU epilogue needs e_src/e_scale/e_shift");
   if (d.epilogue == EPI_GLU_BWD)
-    BSED_CHECK_ARG(d.e_dpool && d.out2 && d.stats && d.ph >= 1 && d.pw >= 1 && d.Hp == d.H / d.ph && d.Wp == d.W / d.pw,
+    BSED_CHECK_ARG(d.e_dpool && d.out2 && d.stats && (d.ph == 1 || d.ph == 2) && (d.pw == 1 || d.pw == 2) &&
+                       d.Hp == d.H / d.ph && d.Wp == d.W / d.pw,
                    "bsed_igemm: GLU_BWD epilogue needs e_dpool/out2/stats and pooled shape");
   if (d.epilogue == EPI_ADD_STATS2)
     BSED_CHECK_ARG(d.out2 && d.e_src && d.stats && d.e_pitch >= d.N, "bsed_igemm: ADD_STATS2 needs out2/e_src/stats");
@@ -442,13 +526,12 @@ static int launch_wgrad(const WgradParams& P, dim3 grid, size_t smem, hipStream_
   return BSED_OK;
 }
 
-extern "C" int bsed_wgrad(const BsedWgradDesc* desc, void* stream) {
+// shape checks + derived launch geometry shared by bsed_wgrad and bsed_wgrad_auto_g
+static int wgrad_prepare(const BsedWgradDesc* desc, WgradParams& P, size_t& smem, dim3& grid_yz) {
   BSED_CHECK_ARG(desc, "bsed_wgrad: null descriptor");
-  WgradParams P;
   P.d = *desc;
   BsedWgradDesc& d = P.d;
-  BSED_CHECK_ARG(d.in && d.dy && d.part, "bsed_wgrad: null tensor");
-  BSED_CHECK_ARG(d.NB > 0 && d.H > 0 && d.W > 0 && d.CIN > 0 && d.N > 0 && d.G > 0, "bsed_wgrad: bad shape");
+  BSED_CHECK_ARG(d.NB > 0 && d.H > 0 && d.W > 0 && d.CIN > 0 && d.N > 0, "bsed_wgrad: bad shape");
   BSED_CHECK_ARG(d.TH * d.TW == IG_TILE_M, "bsed_wgrad: TH*TW must be 128");
   P.lgTW = ilog2_exact(d.TW);
   BSED_CHECK_ARG(P.lgTW >= 0 && d.W % d.TW == 0, "bsed_wgrad: TW must be a power of two dividing W");
@@ -463,17 +546,57 @@ extern "C" int bsed_wgrad(const BsedWgradDesc* desc, void* stream) {
   P.PW = d.TW + 2 * d.hw;
   P.PH = d.TH + 2 * d.hh;
   P.PP = P.PW * P.PH;
-  P.nct = d.CINP / 32;
-  P.dy_off = (P.PP * (d.CINP + 1) + 3) & ~3;
-  const size_t smem = ((size_t)P.dy_off + IG_TILE_M * 32) * sizeof(float);
+  // input channels are contracted in chunks of CC per workgroup (grid.z): 64 for the 9-tap convolutions so that
+  // two workgroups fit in a CU's LDS and one's tile load overlaps the other's MFMAs, 128 for the 1-tap forms
+  P.CC = std::min(d.CINP, d.ntaps == 1 ? 128 : 64);
+  BSED_CHECK_ARG(d.CINP % P.CC == 0 && ilog2_exact(P.CC / 4) >= 0, "bsed_wgrad: CINP must be a power of two >= 32");
+  P.lgc4 = ilog2_exact(P.CC / 4);
+  P.nct = P.CC / 32;
+  P.dy_off = (P.PP * (P.CC + 1) + 3) & ~3;
+  P.pw_magic = ((1 << 20) + P.PW - 1) / P.PW;
+  for (int pos = 0; pos < P.PP; ++pos)
+    BSED_CHECK_ARG(((pos * P.pw_magic) >> 20) == pos / P.PW, "bsed_wgrad: internal: magic division fails for PW=%d", P.PW);
+  // 1-tap contractions have one MFMA per LDS pair: widen the dy tile to 128 channels so the activation tile is
+  // staged once per 4 output tiles (4x fewer HBM/L2 re-reads of `in`) when it fits in LDS
+  // (the 9-tap forms get 2 dy tiles when two workgroups still fit in one CU's LDS: the activation patch is then
+  // staged once per 64 output channels and the per-CU load rate stops being the limiter)
+  P.ntw = 1;
+  for (int cand = 4; cand >= 2; cand >>= 1) {
+    const size_t need = ((size_t)P.dy_off + IG_TILE_M * 32 * cand) * sizeof(float);
+    const size_t budget = d.ntaps == 1 ? 160 * 1024 : 80 * 1024;
+    if (d.NP % (32 * cand) == 0 && d.ntaps * P.nct * cand <= 36 && need <= budget) { P.ntw = cand; break; }
+  }
+  smem = ((size_t)P.dy_off + IG_TILE_M * 32 * P.ntw) * sizeof(float);
   BSED_CHECK_ARG(smem <= 160 * 1024, "bsed_wgrad: tile needs %zu B of LDS", smem);
   const long ntiles = (long)d.NB * d.tilesH * d.tilesW;
   BSED_CHECK_ARG(ntiles < (1L << 31), "bsed_wgrad: too many tiles");
   P.ntiles = (int)ntiles;
-  const int nitems = d.ntaps * P.nct;
+  grid_yz = dim3(1, d.NP / (32 * P.ntw), d.CINP / P.CC);
+  return BSED_OK;
+}
+
+// number of partial slabs G such that G x (n tiles) x (channel chunks) is about three workgroups per CU
+extern "C" int bsed_wgrad_auto_g(const BsedWgradDesc* desc) {
+  WgradParams P;
+  size_t smem;
+  dim3 gyz;
+  if (wgrad_prepare(desc, P, smem, gyz) != BSED_OK) return -1;
+  const long want = ceil_div(768, (long)gyz.y * gyz.z);
+  return (int)std::max<long>(1, std::min<long>(want, P.ntiles));
+}
+
+extern "C" int bsed_wgrad(const BsedWgradDesc* desc, void* stream) {
+  WgradParams P;
+  size_t smem;
+  dim3 gyz;
+  int rc = wgrad_prepare(desc, P, smem, gyz);
+  if (rc != BSED_OK) return rc;
+  BsedWgradDesc& d = P.d;
+  BSED_CHECK_ARG(d.in && d.dy && d.part, "bsed_wgrad: null tensor");
+  BSED_CHECK_ARG(d.G > 0 && d.G <= P.ntiles, "bsed_wgrad: G (%d) must be in 1..%d tiles", d.G, P.ntiles);
+  const int nitems = d.ntaps * P.nct * P.ntw;
   const int slots = ceil_div(nitems, 4);
-  dim3 grid((unsigned)std::min<long>(d.G, ntiles), d.NP / 32);
-  BSED_CHECK_ARG((int)grid.x == d.G, "bsed_wgrad: G (%d) exceeds the number of tiles (%ld)", d.G, ntiles);
+  dim3 grid((unsigned)d.G, gyz.y, gyz.z);
   hipStream_t s = (hipStream_t)stream;
   if (slots <= 1) return launch_wgrad<1>(P, grid, smem, s);
   if (slots <= 2) return launch_wgrad<2>(P, grid, smem, s);

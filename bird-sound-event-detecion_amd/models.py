@@ -246,10 +246,15 @@ class CRNN(_FlatModule):
                 mean = invstd = None
                 scale, shift = ops.bn_eval(co, BN_EPS, bn.weight, bn.bias, bn.running_mean, bn.running_var)
             glu = self.P(f"cnn.glu{i}.linear")
-            wg = ops.pack_weight(glu.weight, 1, co, co, 0, 1, co)
-            pooled, _ = ops.igemm(y, wg, co, B, Hh, Ww, co, bias=glu.bias, epilogue=ops.EPI_GLU_POOL, a_scale=scale,
-                                  a_shift=shift, e_src=y, e_scale=scale, e_shift=shift, pool=(ph, pw), drop_p=drop,
-                                  rng_stream=100 + i, seed=self.seed)
+            if co == 16:
+                # 4 FLOP/B: HBM-bound streaming kernel instead of the MFMA tile kernel (csrc/glu_small.hip)
+                pooled = ops.glu16_fwd(y, scale, shift, glu.weight, glu.bias, B, Hh, Ww, (ph, pw), drop, 100 + i,
+                                       self.seed)
+            else:
+                wg = ops.pack_weight(glu.weight, 1, co, co, 0, 1, co)
+                pooled, _ = ops.igemm(y, wg, co, B, Hh, Ww, co, bias=glu.bias, epilogue=ops.EPI_GLU_POOL,
+                                      a_scale=scale, a_shift=shift, e_src=y, e_scale=scale, e_shift=shift,
+                                      pool=(ph, pw), drop_p=drop, rng_stream=100 + i, seed=self.seed)
             if save:
                 ctx["blocks"].append(dict(inp=a, y=y, mean=mean, invstd=invstd, scale=scale, shift=shift, H=Hh, W=Ww,
                                           cin=cin, co=co, pool=(ph, pw)))
@@ -306,20 +311,28 @@ class CRNN(_FlatModule):
             y = blk["y"]
             glu = self.P(f"cnn.glu{i}.linear")
             bn = self.P(f"cnn.batchnorm{i}")
-            # (1) recompute lin, form d_lin and the gate-branch term
-            wg = ops.pack_weight(glu.weight, 1, co, co, 0, 1, co)
-            tt = torch.empty_like(y)
-            dlin, st = ops.igemm(y, wg, co, B, Hh, Ww, co, bias=glu.bias, epilogue=ops.EPI_GLU_BWD,
-                                 a_scale=blk["scale"], a_shift=blk["shift"], e_src=y, e_scale=blk["scale"],
-                                 e_shift=blk["shift"], e_dpool=dpool, out2=tt, pool=(ph, pw), drop_p=ctx["drop"] if ctx["train"] else 0.0,
-                                 rng_stream=100 + i, seed=seed)
-            ops.stats_to_grad(st, co, 0, glu.bias.grad)
-            # (2) dW_glu = d_lin^T @ bn(y)
-            part, G, KP, NP = ops.wgrad(y, dlin, B, Hh, Ww, co, co, a_scale=blk["scale"], a_shift=blk["shift"])
-            ops.reduce_partials(part, G, 1, KP, NP, co, co, glu.weight.grad, 0, 1, co)
-            # (3) g = d_lin @ W_glu + gate term  (gradient w.r.t. the BatchNorm output), with BN-backward sums
-            wgT = ops.pack_weight(glu.weight, 1, co, co, 0, co, 1)
-            g, st2 = ops.igemm(dlin, wgT, co, B, Hh, Ww, co, epilogue=ops.EPI_ADD_STATS2, out=tt, out2=tt, e_src=y)
+            drop_b = ctx["drop"] if ctx["train"] else 0.0
+            if co == 16:
+                # one streaming pass: y, d_pooled -> g + partials of dW_glu, db_glu and the BN-backward sums
+                g, pdw, pdb, st2, G = ops.glu16_bwd(y, blk["scale"], blk["shift"], glu.weight, glu.bias,
+                                                    dpool.contiguous(), B, Hh, Ww, (ph, pw), drop_b, 100 + i, seed)
+                ops.reduce_partials(pdw, G, 1, 16, 16, 16, 16, glu.weight.grad, 0, 16, 1)
+                ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
+            else:
+                # (1) recompute lin, form d_lin and the gate-branch term
+                wg = ops.pack_weight(glu.weight, 1, co, co, 0, 1, co)
+                tt = torch.empty_like(y)
+                dlin, st = ops.igemm(y, wg, co, B, Hh, Ww, co, bias=glu.bias, epilogue=ops.EPI_GLU_BWD,
+                                     a_scale=blk["scale"], a_shift=blk["shift"], e_src=y, e_scale=blk["scale"],
+                                     e_shift=blk["shift"], e_dpool=dpool, out2=tt, pool=(ph, pw), drop_p=drop_b,
+                                     rng_stream=100 + i, seed=seed)
+                ops.stats_to_grad(st, co, 0, glu.bias.grad)
+                # (2) dW_glu = d_lin^T @ bn(y)
+                part, G, KP, NP = ops.wgrad(y, dlin, B, Hh, Ww, co, co, a_scale=blk["scale"], a_shift=blk["shift"])
+                ops.reduce_partials(part, G, 1, KP, NP, co, co, glu.weight.grad, 0, 1, co)
+                # (3) g = d_lin @ W_glu + gate term  (gradient w.r.t. the BatchNorm output), with BN-backward sums
+                wgT = ops.pack_weight(glu.weight, 1, co, co, 0, co, 1)
+                g, st2 = ops.igemm(dlin, wgT, co, B, Hh, Ww, co, epilogue=ops.EPI_ADD_STATS2, out=tt, out2=tt, e_src=y)
             # (4) BatchNorm backward -> d_y in place
             ops.bn_bwd(st2, co, float(B * Hh * Ww), bn.weight, blk["mean"], blk["invstd"], bn.weight.grad,
                        bn.bias.grad, g, y)

@@ -151,18 +151,21 @@ def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=Non
     TH, TW = tile_for(W)
     CINP, NP = round_up(CIN, 32), round_up(N, 32)
     ntiles = NB * ((H + TH - 1) // TH) * (W // TW)
-    G = max(1, min(ntiles, 1024 // (NP // 32)))
-    part = torch.empty((G, len(taps), CINP, NP), device=inp.device, dtype=torch.float32)
-    d.in_ = _dp(inp, in_offset); d.dy = _dp(dy, dy_offset); d.part = _p(part)
+    d.in_ = _dp(inp, in_offset); d.dy = _dp(dy, dy_offset)
     d.a_scale = _p(a_scale); d.a_shift = _p(a_shift)
     d.in_pitch = CIN if in_pitch is None else in_pitch
     d.dy_pitch = N if dy_pitch is None else dy_pitch
-    d.NB, d.H, d.W, d.CIN, d.CINP, d.N, d.NP, d.G = NB, H, W, CIN, CINP, N, NP, G
+    d.NB, d.H, d.W, d.CIN, d.CINP, d.N, d.NP, d.G = NB, H, W, CIN, CINP, N, NP, 0
     d.TH, d.TW = TH, TW
     d.hh = max(abs(t[0]) for t in taps); d.hw = max(abs(t[1]) for t in taps)
     d.ntaps = len(taps)
     for i, (a, b) in enumerate(taps):
         d.dh[i], d.dw[i] = a, b
+    G = L.lib().bsed_wgrad_auto_g(ctypes.byref(d))
+    if G <= 0:
+        raise L.BsedError("bsed_wgrad_auto_g: " + L.lib().bsed_last_error().decode())
+    part = torch.empty((G, len(taps), CINP, NP), device=inp.device, dtype=torch.float32)
+    d.part, d.G = _p(part), G
     _launch(("wgrad", 0, len(taps), CIN, N, H, W), 2.0 * NB * H * W * len(taps) * CIN * N,
             lambda: L.call("bsed_wgrad", ctypes.byref(d), L.stream()))
     return part, G, CINP, NP
@@ -203,6 +206,30 @@ def conv0_wgrad(x, dy, NB, H, W, CO):
     part = torch.empty((G, 9, CO), device=x.device, dtype=torch.float32)
     L.call("bsed_conv0_wgrad", L.ptr(x), L.ptr(dy), L.ptr(part), _i(G), _i(NB), _i(H), _i(W), _i(CO), L.stream())
     return part, G
+
+
+def glu16_fwd(y, scale, shift, wg, bg, B, H, W, pool, drop_p, rng_stream, seed):
+    ph, pw = pool
+    out = torch.empty((B, H // ph, W // pw, 16), device=y.device, dtype=torch.float32)
+    L.call("bsed_glu16_fwd", L.ptr(y), L.ptr(scale), L.ptr(shift), _fp(_dp(wg)), _fp(_dp(bg)), L.ptr(out), _i(B), _i(H),
+           _i(W), _i(16), _i(ph), _i(pw), ctypes.c_float(drop_p), ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed),
+           L.stream())
+    return out
+
+
+def glu16_bwd(y, scale, shift, wg, bg, dpool, B, H, W, pool, drop_p, rng_stream, seed):
+    """returns (g, part_dw (G,16,16), part_db (G,2,16), part_st (G,2,16), G)"""
+    ph, pw = pool
+    dev = y.device
+    G = int(min(2048, B * H))
+    g = torch.empty_like(y)
+    part_dw = torch.empty((G, 16, 16), device=dev, dtype=torch.float32)
+    part_db = torch.empty((G, 2, 16), device=dev, dtype=torch.float32)
+    part_st = torch.empty((G, 2, 16), device=dev, dtype=torch.float32)
+    L.call("bsed_glu16_bwd", L.ptr(y), L.ptr(scale), L.ptr(shift), _fp(_dp(wg)), _fp(_dp(bg)), L.ptr(dpool), L.ptr(g),
+           L.ptr(part_dw), L.ptr(part_db), L.ptr(part_st), _i(G), _i(B), _i(H), _i(W), _i(16), _i(ph), _i(pw),
+           ctypes.c_float(drop_p), ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream())
+    return g, part_dw, part_db, part_st, G
 
 
 def bn_finalize(stats, C, count, eps, momentum, gamma, beta, rmean, rvar, nbt):

@@ -122,6 +122,8 @@ typedef struct BsedWgradDesc {
 } BsedWgradDesc;
 
 int bsed_wgrad(const BsedWgradDesc* desc /*host*/, void* stream);
+/* recommended number of partial slabs G for this shape (pointers in desc are ignored) */
+int bsed_wgrad_auto_g(const BsedWgradDesc* desc /*host*/);
 /* dst[tap*s_tap + k*s_k + n*s_n] (+)= sum_g part[g][tap][k][n]   (k < K, n < N) */
 int bsed_reduce_partials(const float* part, int G, int ntaps, int KP, int NP, int K, int N, float* dst,
                          long s_tap, long s_k, long s_n, int accumulate, void* stream);
@@ -165,6 +167,19 @@ int bsed_colsum(const float* in, long M, int C, int pitch, float* part, int G, f
                 void* scratch, void* stream);
 /* nn.Dropout(p) with a stateless Philox mask: out = in * keep/(1-p); the same call is its backward */
 int bsed_dropout(const float* in, float* out, long n, float p, uint32_t rng_stream, uint64_t seed, void* stream);
+
+/* GLU stage of a 16-channel block as HBM-bound streaming kernels (csrc/glu_small.hip): same math as
+ * bsed_igemm(BSED_EPI_GLU_POOL) / the GLU backward chain (src/models/CNN.py:5-16,59-67), one pass over y.
+ *   forward : y (B,H,W,16) -> pooled (B,H/ph,W/pw,16)
+ *   backward: y, dpool -> g = dL/d(BN output) (B,H,W,16), per-workgroup partials part_dw (G,16,16),
+ *             part_db (G,2,16) [slot 0], part_st (G,2,16) = (sum g, sum g*y) for bsed_bn_bwd */
+int bsed_glu16_fwd(const float* y, const float* scale, const float* shift, const float* wg, const float* bg,
+                   float* out, int B, int H, int W, int C, int ph, int pw, float drop_p, uint32_t rng_stream,
+                   uint64_t seed, void* stream);
+int bsed_glu16_bwd(const float* y, const float* scale, const float* shift, const float* wg, const float* bg,
+                   const float* dpool, float* g_out, float* part_dw, float* part_db, float* part_st, int G, int B,
+                   int H, int W, int C, int ph, int pw, float drop_p, uint32_t rng_stream, uint64_t seed,
+                   void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Bidirectional GRU recurrence (csrc/gru.hip); replaces nn.GRU of src/models/RNN.py:7-16.
