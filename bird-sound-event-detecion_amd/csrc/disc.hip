@@ -1,0 +1,268 @@
+// Clip-level domain discriminator pieces (reference Clip_Discriminator, src/models/CRNN_GRL.py:16-53, fed through
+// the gradient-reverse layer of src/DA/grl.py:12-22 and the BCE of src/DA/cdan_frame.py:89-119).
+//
+// The five 3x3 / stride-2 / pad-0 convolutions are lowered to GEMMs on the existing fp32-MFMA kernels:
+//   forward   y = im2col(act) @ W            (bsed_igemm, BSED_EPI_STATS for the BatchNorm statistics)
+//   weights   dW = im2col(act)^T @ dY         (bsed_wgrad)
+//   data      d_act = col2im(dY @ W^T)        (bsed_igemm + col2im)
+// so this file only holds the streaming glue around them:
+//   im2col_s2_kernel : gather with BatchNorm-apply + LeakyReLU(0.2) of the previous layer fused into the load
+//   col2im_s2_kernel : the adjoint gather, fused with LeakyReLU backward and the BatchNorm-backward sums, or with
+//                      the -lambda of the gradient-reverse layer for the first layer
+//   disc_head_kernel : BN5 + LeakyReLU + AdaptiveAvgPool2d((2,1)) + Linear(16,1) + sigmoid + BCE, forward and backward
+// Spatial layout: the reference permutes the (N,T,256) embedding to an image (256 x T); here the image is kept
+// as (H = T, W = 256) -- the embedding's own memory order -- and the 3x3 kernels are read transposed instead.
+#include "bsed_common.h"
+#include "../../include/bsed.h"
+#include <algorithm>
+
+#define LEAKY 0.2f
+
+// col[(n,ho,wo)][(dw*3+dh)*CP + c] = f(act[n][2ho+dh][2wo+dw][c]),  f = leaky(x*scale+shift) or identity
+__global__ void im2col_s2_kernel(const float* __restrict__ act, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, float* __restrict__ col, int N, int Hi, int Wi, int C,
+                                 int CP, int KW, int Ho, int Wo) {
+  const int cq = CP / 4;                       // float4 groups per tap (C == 1: handled by the scalar branch)
+  const long total = (long)N * Ho * Wo * 9 * cq;
+  if (C == 1) {
+    const long tot1 = (long)N * Ho * Wo * KW;  // KW = 16: 9 taps + zero padding
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot1; e += (long)gridDim.x * blockDim.x) {
+      const int t = (int)(e % KW);
+      const long p = e / KW;
+      float v = 0.f;
+      if (t < 9) {
+        const int dw = t / 3, dh = t % 3;
+        const int wo = (int)(p % Wo);
+        const long r = p / Wo;
+        const int ho = (int)(r % Ho);
+        const long n = r / Ho;
+        v = act[(n * Hi + 2 * ho + dh) * Wi + 2 * wo + dw];
+      }
+      col[e] = v;
+    }
+    return;
+  }
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % cq);
+    long r = e / cq;
+    const int t = (int)(r % 9); r /= 9;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho);
+    const long n = r / Ho;
+    const int dw = t / 3, dh = t % 3;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c = 4 * c4;
+    if (c < C) {
+      v = *reinterpret_cast<const float4*>(act + ((n * Hi + 2 * ho + dh) * Wi + 2 * wo + dw) * (long)C + c);
+      if (scale) {
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+        v.x = v.x > 0.f ? v.x : LEAKY * v.x; v.y = v.y > 0.f ? v.y : LEAKY * v.y;
+        v.z = v.z > 0.f ? v.z : LEAKY * v.z; v.w = v.w > 0.f ? v.w : LEAKY * v.w;
+      }
+    }
+    *reinterpret_cast<float4*>(col + (((n * Ho + ho) * Wo + wo) * 9 + t) * (long)CP + c) = v;
+  }
+}
+
+// d_act[n][h][w][c] = sum over taps with (h-dh, w-dw) even and in range of dcol[(n,(h-dh)/2,(w-dw)/2)][(dw*3+dh)*CP+c]
+//   C > 1 : g = d_act * leaky'(y*scale+shift) written to out, per-block partial sums (sum g, sum g*y) to stats
+//   C == 1: out = d_act * out_scale   (gradient-reverse layer: out_scale = -lambda)
+__global__ __launch_bounds__(256) void col2im_s2_kernel(const float* __restrict__ dcol, const float* __restrict__ y,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        float* __restrict__ out, float* __restrict__ stats, int N, int Hi,
+                                                        int Wi, int C, int CP, int KW, int Ho, int Wo, float out_scale) {
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x;
+  if (C == 1) {
+    const long tot = (long)N * Hi * Wi;
+    for (long e = (long)blockIdx.x * blockDim.x + tid; e < tot; e += (long)gridDim.x * blockDim.x) {
+      const int w = (int)(e % Wi);
+      const long r = e / Wi;
+      const int h = (int)(r % Hi);
+      const long n = r / Hi;
+      float a = 0.f;
+      for (int dh = 0; dh < 3; ++dh) {
+        const int hh = h - dh;
+        if (hh < 0 || (hh & 1) || (hh >> 1) >= Ho) continue;
+        for (int dw = 0; dw < 3; ++dw) {
+          const int ww = w - dw;
+          if (ww < 0 || (ww & 1) || (ww >> 1) >= Wo) continue;
+          a += dcol[((n * Ho + (hh >> 1)) * Wo + (ww >> 1)) * (long)KW + dw * 3 + dh];
+        }
+      }
+      out[e] = a * out_scale;
+    }
+    return;
+  }
+  const int cq = C / 4;
+  const long tot = (long)N * Hi * Wi * cq;
+  // one block = 256 consecutive float4 groups; blocks are NOT grid-strided so the partial-stat slot is unique
+  const long e = (long)blockIdx.x * 256 + tid;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f), gy = make_float4(0.f, 0.f, 0.f, 0.f);
+  int c = 0;
+  if (e < tot) {
+    const int c4 = (int)(e % cq);
+    c = 4 * c4;
+    long r = e / cq;
+    const int w = (int)(r % Wi); r /= Wi;
+    const int h = (int)(r % Hi);
+    const long n = r / Hi;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int dh = 0; dh < 3; ++dh) {
+      const int hh = h - dh;
+      if (hh < 0 || (hh & 1) || (hh >> 1) >= Ho) continue;
+      for (int dw = 0; dw < 3; ++dw) {
+        const int ww = w - dw;
+        if (ww < 0 || (ww & 1) || (ww >> 1) >= Wo) continue;
+        const float4 v = *reinterpret_cast<const float4*>(
+            dcol + (((n * Ho + (hh >> 1)) * Wo + (ww >> 1)) * 9 + dw * 3 + dh) * (long)CP + c);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    }
+    const float4 yv = *reinterpret_cast<const float4*>(y + e * 4);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+    g.x = a.x * (fmaf(yv.x, sc.x, sh.x) > 0.f ? 1.f : LEAKY);
+    g.y = a.y * (fmaf(yv.y, sc.y, sh.y) > 0.f ? 1.f : LEAKY);
+    g.z = a.z * (fmaf(yv.z, sc.z, sh.z) > 0.f ? 1.f : LEAKY);
+    g.w = a.w * (fmaf(yv.w, sc.w, sh.w) > 0.f ? 1.f : LEAKY);
+    *reinterpret_cast<float4*>(out + e * 4) = g;
+    gy = make_float4(g.x * yv.x, g.y * yv.y, g.z * yv.z, g.w * yv.w);
+  }
+  // per-block sums per channel: thread t holds channel group (e % cq); 256 % cq == 0 for cq in {4,8,16,32}
+  float* r8 = red + tid * 8;
+  r8[0] = g.x; r8[1] = g.y; r8[2] = g.z; r8[3] = g.w; r8[4] = gy.x; r8[5] = gy.y; r8[6] = gy.z; r8[7] = gy.w;
+  __syncthreads();
+  if (tid < 2 * C) {
+    const int which = tid / C, ch = tid % C;
+    const int q0 = (int)(((long)blockIdx.x * 256) % cq);  // channel group of thread 0
+    float s = 0.f;
+    // threads whose group == ch/4: t with (q0 + t) % cq == ch/4
+    int t0 = (ch / 4 - q0) % cq;
+    if (t0 < 0) t0 += cq;
+    for (int t = t0; t < 256; t += cq) s += red[t * 8 + which * 4 + (ch & 3)];
+    stats[((size_t)blockIdx.x * 2 + which) * C + ch] = s;
+  }
+}
+
+// tail of the discriminator for one sample per thread: y5 (N,H5,W5,8) -> BN + LeakyReLU -> AdaptiveAvgPool over the
+// feature axis (W5 = 7 -> bins [0,4), [3,7)) and all of time -> Linear(16,1) -> sigmoid -> BCE(label_n), and back.
+__global__ void disc_head_kernel(const float* __restrict__ y5, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, const float* __restrict__ wl, const float* __restrict__ bl,
+                                 int N, int Ns, int H5, int W5, int train, float* __restrict__ d_out,
+                                 float* __restrict__ g5, float* __restrict__ stats /*(N,2,8)*/,
+                                 float* __restrict__ dwl_part /*(N,2,16)*/, float* __restrict__ dbl_part /*(N,2,1)*/,
+                                 float* __restrict__ loss_part /*(N,2,1)*/) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  constexpr int C = 8;
+  const float* yn = y5 + (size_t)n * H5 * W5 * C;
+  // adaptive bins over W5 (PyTorch: start = floor(i*W/2), end = ceil((i+1)*W/2))
+  const int b0s = 0, b0e = (W5 + 1) / 2, b1s = W5 / 2, b1e = W5;
+  float pooled[C][2];
+  for (int c = 0; c < C; ++c) { pooled[c][0] = 0.f; pooled[c][1] = 0.f; }
+  for (int h = 0; h < H5; ++h)
+    for (int w = 0; w < W5; ++w)
+      for (int c = 0; c < C; ++c) {
+        float a = fmaf(yn[(h * W5 + w) * C + c], scale[c], shift[c]);
+        a = a > 0.f ? a : LEAKY * a;
+        if (w >= b0s && w < b0e) pooled[c][0] += a;
+        if (w >= b1s && w < b1e) pooled[c][1] += a;
+      }
+  const float inv0 = 1.0f / (float)(H5 * (b0e - b0s)), inv1 = 1.0f / (float)(H5 * (b1e - b1s));
+  float z = bl[0];
+  for (int c = 0; c < C; ++c) {
+    pooled[c][0] *= inv0; pooled[c][1] *= inv1;
+    z = fmaf(wl[c * 2], pooled[c][0], z);
+    z = fmaf(wl[c * 2 + 1], pooled[c][1], z);
+  }
+  const float d = sigmoidf_(z);
+  d_out[n] = d;
+  if (!train) return;
+  const float lab = n < Ns ? 1.f : 0.f;
+  loss_part[n * 2] = -(lab * fmaxf(logf(d), -100.f) + (1.f - lab) * fmaxf(logf(1.f - d), -100.f));
+  loss_part[n * 2 + 1] = 0.f;
+  const float dz = (d - lab) / fmaxf((1.f - d) * d, 1e-12f) / (float)N * d * (1.f - d);
+  dbl_part[n * 2] = dz; dbl_part[n * 2 + 1] = 0.f;
+  float dp[C][2];
+  for (int c = 0; c < C; ++c) {
+    dwl_part[(size_t)n * 32 + c * 2] = dz * pooled[c][0];
+    dwl_part[(size_t)n * 32 + c * 2 + 1] = dz * pooled[c][1];
+    dp[c][0] = dz * wl[c * 2] * inv0;
+    dp[c][1] = dz * wl[c * 2 + 1] * inv1;
+  }
+  for (int j = 0; j < 16; ++j) dwl_part[(size_t)n * 32 + 16 + j] = 0.f;
+  float sg[C], sgy[C];
+  for (int c = 0; c < C; ++c) { sg[c] = 0.f; sgy[c] = 0.f; }
+  for (int h = 0; h < H5; ++h)
+    for (int w = 0; w < W5; ++w)
+      for (int c = 0; c < C; ++c) {
+        const float yv = yn[(h * W5 + w) * C + c];
+        const float xn = fmaf(yv, scale[c], shift[c]);
+        float da = 0.f;
+        if (w >= b0s && w < b0e) da += dp[c][0];
+        if (w >= b1s && w < b1e) da += dp[c][1];
+        const float g = da * (xn > 0.f ? 1.f : LEAKY);
+        g5[((size_t)n * H5 * W5 + h * W5 + w) * C + c] = g;
+        sg[c] += g;
+        sgy[c] = fmaf(g, yv, sgy[c]);
+      }
+  for (int c = 0; c < C; ++c) {
+    stats[((size_t)n * 2 + 0) * C + c] = sg[c];
+    stats[((size_t)n * 2 + 1) * C + c] = sgy[c];
+  }
+}
+
+extern "C" int bsed_im2col_s2(const float* act, const float* scale, const float* shift, float* col, int N, int Hi, int Wi,
+                              int C, int CP, void* stream) {
+  BSED_CHECK_ARG(act && col && N > 0 && Hi >= 3 && Wi >= 3, "bsed_im2col_s2: bad argument");
+  BSED_CHECK_ARG(C == 1 || (C % 4 == 0 && CP >= C && CP % 4 == 0), "bsed_im2col_s2: C must be 1 or a multiple of 4");
+  BSED_CHECK_ARG(C == 1 || ((scale == nullptr) == (shift == nullptr)), "bsed_im2col_s2: scale/shift come together");
+  const int Ho = (Hi - 3) / 2 + 1, Wo = (Wi - 3) / 2 + 1;
+  const int KW = C == 1 ? 16 : 9 * CP;
+  const long total = C == 1 ? (long)N * Ho * Wo * KW : (long)N * Ho * Wo * 9 * (CP / 4);
+  hipLaunchKernelGGL(im2col_s2_kernel, dim3((unsigned)std::min<long>(ceil_div(total, 256), 16384)), dim3(256), 0,
+                     (hipStream_t)stream, act, scale, shift, col, N, Hi, Wi, C, CP, KW, Ho, Wo);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_col2im_s2_num_blocks(int N, int Hi, int Wi, int C) {
+  return C == 1 ? 0 : ceil_div((long)N * Hi * Wi * (C / 4), 256);
+}
+
+extern "C" int bsed_col2im_s2(const float* dcol, const float* y, const float* scale, const float* shift, float* out,
+                              float* stats, int N, int Hi, int Wi, int C, int CP, float out_scale, void* stream) {
+  BSED_CHECK_ARG(dcol && out && N > 0 && Hi >= 3 && Wi >= 3, "bsed_col2im_s2: bad argument");
+  const int Ho = (Hi - 3) / 2 + 1, Wo = (Wi - 3) / 2 + 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 1) {
+    const long tot = (long)N * Hi * Wi;
+    hipLaunchKernelGGL(col2im_s2_kernel, dim3((unsigned)std::min<long>(ceil_div(tot, 256), 16384)), dim3(256), 0, s, dcol,
+                       y, scale, shift, out, stats, N, Hi, Wi, C, CP, 16, Ho, Wo, out_scale);
+  } else {
+    BSED_CHECK_ARG(y && scale && shift && stats, "bsed_col2im_s2: y/scale/shift/stats needed for C > 1");
+    BSED_CHECK_ARG(C % 4 == 0 && 256 % (C / 4) == 0 && C <= 128 && CP >= C, "bsed_col2im_s2: C must be 16..128, power of two");
+    const long blocks = ceil_div((long)N * Hi * Wi * (C / 4), 256);
+    BSED_CHECK_ARG(blocks < (1L << 31), "bsed_col2im_s2: too many blocks");
+    hipLaunchKernelGGL(col2im_s2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dcol, y, scale, shift, out, stats, N, Hi,
+                       Wi, C, CP, 9 * CP, Ho, Wo, out_scale);
+  }
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_disc_head(const float* y5, const float* scale, const float* shift, const float* wl, const float* bl,
+                              int N, int Ns, int H5, int W5, int C5, int train, float* d_out, float* g5, float* stats,
+                              float* dwl_part, float* dbl_part, float* loss_part, void* stream) {
+  BSED_CHECK_ARG(y5 && scale && shift && wl && bl && d_out && N > 0 && Ns >= 0 && Ns <= N, "bsed_disc_head: bad argument");
+  BSED_CHECK_ARG(C5 == 8 && H5 > 0 && W5 >= 2, "bsed_disc_head: built for the 8-channel last layer");
+  BSED_CHECK_ARG(!train || (g5 && stats && dwl_part && dbl_part && loss_part), "bsed_disc_head: training needs the gradient buffers");
+  hipLaunchKernelGGL(disc_head_kernel, dim3(ceil_div(N, 64)), dim3(64), 0, (hipStream_t)stream, y5, scale, shift, wl, bl,
+                     N, Ns, H5, W5, train, d_out, g5, stats, dwl_part, dbl_part, loss_part);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}

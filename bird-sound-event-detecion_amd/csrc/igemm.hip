@@ -348,14 +348,16 @@ __global__ __launch_bounds__(IG_THREADS) void wgrad_kernel(const WgradParams P) 
       const int mk = kp + lh;
       const float* dyrow = DYs + mk * DYW;
       const float* xrow = Xs + (((mk >> P.lgTW) + p.hh) * PW + (mk & (p.TW - 1)) + p.hw) * XP;
+      // straight-line on purpose: padded slots (it >= nitems) repeat item 0 and are dropped in the epilogue, so
+      // the LDS reads of all slots issue ahead of the MFMAs instead of one exposed LDS latency per MFMA
+      float av[MAXS], bv[MAXS];
 #pragma unroll
       for (int s = 0; s < MAXS; ++s) {
-        if (valid[s]) {
-          const float a = xrow[xoff[s]];
-          const float b = dyrow[boff[s]];
-          acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[s], 0, 0, 0);
-        }
+        av[s] = xrow[xoff[s]];
+        bv[s] = dyrow[boff[s]];
       }
+#pragma unroll
+      for (int s = 0; s < MAXS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[s], 0, 0, 0);
     }
   }
   const int NPo = gridDim.y * DYW;
@@ -548,8 +550,10 @@ static int wgrad_prepare(const BsedWgradDesc* desc, WgradParams& P, size_t& smem
   P.PP = P.PW * P.PH;
   // input channels are contracted in chunks of CC per workgroup (grid.z): 64 for the 9-tap convolutions so that
   // two workgroups fit in a CU's LDS and one's tile load overlaps the other's MFMAs, 128 for the 1-tap forms
-  P.CC = std::min(d.CINP, d.ntaps == 1 ? 128 : 64);
-  BSED_CHECK_ARG(d.CINP % P.CC == 0 && ilog2_exact(P.CC / 4) >= 0, "bsed_wgrad: CINP must be a power of two >= 32");
+  P.CC = 32;
+  for (int cand = (d.ntaps == 1 ? 128 : 64); cand >= 32; cand >>= 1)
+    if (d.CINP % cand == 0) { P.CC = cand; break; }
+  BSED_CHECK_ARG(d.CINP % P.CC == 0 && d.CINP / P.CC <= 65535, "bsed_wgrad: CINP must be a multiple of 32");
   P.lgc4 = ilog2_exact(P.CC / 4);
   P.nct = P.CC / 32;
   P.dy_off = (P.PP * (P.CC + 1) + 3) & ~3;

@@ -54,6 +54,10 @@ __global__ void scale_kernel(float* __restrict__ x, long n, float s) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= s;
 }
 
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, long n, float a) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = fmaf(a, x[i], y[i]);
+}
+
 static inline unsigned flat_grid(long n) { return (unsigned)std::min<long>(std::max<long>(ceil_div(n, 256), 1), 4096); }
 
 extern "C" int bsed_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
@@ -86,6 +90,13 @@ extern "C" int bsed_ema_update(float* ema, const float* p, long n, float alpha, 
 extern "C" int bsed_ema_update_i64(long long* ema, const long long* p, int n, float alpha, void* stream) {
   BSED_CHECK_ARG(ema && p && n > 0, "bsed_ema_update_i64: bad argument");
   hipLaunchKernelGGL(ema_i64_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, (hipStream_t)stream, ema, p, n, alpha);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_axpy(float* y, const float* x, long n, float a, void* stream) {
+  BSED_CHECK_ARG(y && x && n > 0, "bsed_axpy: bad argument");
+  hipLaunchKernelGGL(axpy_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, y, x, n, a);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }

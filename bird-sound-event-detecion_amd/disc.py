@@ -1,0 +1,237 @@
+"""Domain-adversarial head on the GPU.
+
+  Clip_Discriminator(input_dim, dropout=0)            <- reference src/models/CRNN_GRL.py:16-53
+  ConditionalDomainAdversarialLoss(discriminator)      <- reference src/DA/cdan_frame.py:16-119 as it executes:
+        d = D(GRL_lambda(cat(f_s, f_t)));  loss = BCE(d, [1]*B_s + [0]*B_t)
+        lambda_i = 2/(1+exp(-i/1000)) - 1, i += 1 per call   (WarmStartGradientReverseLayer, src/DA/grl.py:33-73)
+The convolutions run as im2col + the fp32-MFMA GEMM kernels (csrc/disc.hip, csrc/igemm.hip).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .models import _FlatModule
+
+D_EPS, D_MOM = 1e-5, 0.1
+D_CH = [1, 128, 64, 32, 16, 8]
+
+
+def _i(v):
+    return ctypes.c_int(v)
+
+
+def _im2col(act, scale, shift, N, Hi, Wi, C, CP):
+    Ho, Wo = (Hi - 3) // 2 + 1, (Wi - 3) // 2 + 1
+    K = 16 if C == 1 else 9 * CP
+    col = torch.empty((N * Ho * Wo, K), device=act.device, dtype=torch.float32)
+    L.call("bsed_im2col_s2", L.ptr(act), L.ptr(scale), L.ptr(shift), L.ptr(col), _i(N), _i(Hi), _i(Wi), _i(C), _i(CP),
+           L.stream())
+    return col, Ho, Wo, K
+
+
+def _col2im(dcol, y, scale, shift, N, Hi, Wi, C, CP, out_scale=1.0):
+    dev = dcol.device
+    out = torch.empty((N, Hi, Wi, C), device=dev, dtype=torch.float32)
+    stats = None
+    if C > 1:
+        nb = L.lib().bsed_col2im_s2_num_blocks(N, Hi, Wi, C)
+        stats = torch.empty((nb, 2, C), device=dev, dtype=torch.float32)
+    L.call("bsed_col2im_s2", L.ptr(dcol), L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(out), L.ptr(stats), _i(N), _i(Hi),
+           _i(Wi), _i(C), _i(CP), ctypes.c_float(out_scale), L.stream())
+    return out, stats
+
+
+class Clip_Discriminator(_FlatModule):
+    def __init__(self, input_dim=None, dropout=0, device="cuda"):
+        super().__init__()
+        L._require_gpu()
+        pspecs, bspecs = [], []
+        for k in range(1, 6):
+            pspecs += [(f"conv_{k}.weight", (D_CH[k], D_CH[k - 1], 3, 3)), (f"conv_{k}.bias", (D_CH[k],))]
+        pspecs += [("dense_d.weight", (1, 16)), ("dense_d.bias", (1,))]
+        for k in range(1, 6):
+            pspecs += [(f"bn_{k}.weight", (D_CH[k],)), (f"bn_{k}.bias", (D_CH[k],))]
+            bspecs += [(f"bn_{k}.running_mean", (D_CH[k],)), (f"bn_{k}.running_var", (D_CH[k],))]
+        self._build(pspecs, bspecs, device)
+        self.nbt = torch.zeros(5, device=device, dtype=torch.int64)
+        for k in range(1, 6):
+            self.P(f"bn_{k}").register_buffer("num_batches_tracked", self.nbt[k - 1])
+        self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self):
+        for name, p in self.named_parameters():
+            if name.startswith("bn_"):
+                p.fill_(1.0 if name.endswith("weight") else 0.0)
+            elif name.endswith("weight"):
+                b = 1 / math.sqrt(p[0].numel())
+                p.uniform_(-b, b)
+            else:
+                b = 1 / math.sqrt(self.P(name[:-4] + "weight")[0].numel())
+                p.uniform_(-b, b)
+        for name, b in self.named_buffers():
+            if name.endswith("running_var"):
+                b.fill_(1.0)
+            else:
+                b.zero_()
+
+    # ------------------------------------------------------------------ forward / backward
+    def _fwd_weight(self, k):
+        """[K][NP] GEMM operand of conv_k: row (dw*3+dh)*CP + c  (== kh*3+kw of the reference orientation)"""
+        co, cin = D_CH[k], D_CH[k - 1]
+        w = self.P(f"conv_{k}.weight")
+        wpk = ops.pack_weight(w, 9, cin, co, 1, 9, cin * 9)            # [9][cin][NP]
+        NP = wpk.shape[2]
+        if cin == 1:
+            full = torch.zeros((1, 16, NP), device=w.device, dtype=torch.float32)
+            full[0, :9] = wpk[:, 0]
+            return full, 1
+        CP = max(cin, 32)
+        if CP != cin:
+            full = torch.zeros((9, CP, NP), device=w.device, dtype=torch.float32)
+            full[:, :cin] = wpk
+            wpk = full
+        return wpk.view(1, 9 * CP, NP), CP
+
+    def _bwd_weight(self, k, CP):
+        """[co_pad][NP] operand of dcol = dY @ W^T: column (dw*3+dh)*CP + c"""
+        co, cin = D_CH[k], D_CH[k - 1]
+        w = self.P(f"conv_{k}.weight").detach()
+        K = 16 if cin == 1 else 9 * CP
+        cop = ops.round_up(co, 16)
+        full = torch.zeros((1, cop, ops.round_up(K, 32)), device=w.device, dtype=torch.float32)
+        if cin == 1:
+            full[0, :co, :9] = w.view(co, 9)
+        else:
+            wt = w.view(co, cin, 9).permute(0, 2, 1)                    # (co, 9, cin)
+            tmp = torch.zeros((co, 9, CP), device=w.device, dtype=torch.float32)
+            tmp[:, :, :cin] = wt
+            full[0, :co, :K] = tmp.view(co, K)
+        return full, K, cop
+
+    def run_forward(self, feat, n_source=None, save=True):
+        """feat (N,T,256) -> (d (N,), ctx).  In train mode (and with n_source) also prepares the BCE backward."""
+        feat = feat.contiguous().float()
+        N, T, F = feat.shape
+        train = self.training
+        act, scale, shift = feat, None, None
+        Hi, Wi = T, F
+        layers = []
+        for k in range(1, 6):
+            co, cin = D_CH[k], D_CH[k - 1]
+            wpk, CP = self._fwd_weight(k)
+            col, Ho, Wo, K = _im2col(act, scale, shift, N, Hi, Wi, cin, CP)
+            M = N * Ho * Wo
+            y, stats = ops.igemm(col, wpk, co, 1, M, 1, K, bias=self.P(f"conv_{k}.bias"),
+                                 epilogue=ops.EPI_STATS if train else ops.EPI_PLAIN)
+            bn = self.P(f"bn_{k}")
+            if train:
+                mean, invstd, scale, shift = ops.bn_finalize(stats, co, float(M), D_EPS, D_MOM, bn.weight, bn.bias,
+                                                             bn.running_mean, bn.running_var, self.nbt[k - 1:k])
+            else:
+                mean = invstd = None
+                scale, shift = ops.bn_eval(co, D_EPS, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+            y = y.view(N, Ho, Wo, co)
+            if save:
+                layers.append(dict(col=col, y=y, mean=mean, invstd=invstd, scale=scale, shift=shift, Hi=Hi, Wi=Wi,
+                                   Ho=Ho, Wo=Wo, K=K, CP=CP, M=M))
+            act, Hi, Wi = y, Ho, Wo
+        dev = feat.device
+        d = torch.empty((N,), device=dev, dtype=torch.float32)
+        do_loss = train and n_source is not None
+        g5 = stats5 = dwl = dbl = lossp = None
+        if do_loss:
+            g5 = torch.empty_like(act)
+            stats5 = torch.empty((N, 2, 8), device=dev, dtype=torch.float32)
+            dwl = torch.empty((N, 2, 16), device=dev, dtype=torch.float32)
+            dbl = torch.empty((N, 2, 1), device=dev, dtype=torch.float32)
+            lossp = torch.empty((N, 2, 1), device=dev, dtype=torch.float32)
+        dense = self.P("dense_d")
+        L.call("bsed_disc_head", L.ptr(act), L.ptr(scale), L.ptr(shift), ctypes.c_void_p(dense.weight.data_ptr()),
+               ctypes.c_void_p(dense.bias.data_ptr()), _i(N), _i(n_source or 0), _i(Hi), _i(Wi), _i(8),
+               _i(1 if do_loss else 0), L.ptr(d), L.ptr(g5), L.ptr(stats5), L.ptr(dwl), L.ptr(dbl), L.ptr(lossp),
+               L.stream())
+        ctx = dict(N=N, T=T, F=F, layers=layers, g5=g5, stats5=stats5, dwl=dwl, dbl=dbl, lossp=lossp) if save else None
+        return d, ctx
+
+    def run_backward(self, ctx, grl_coeff):
+        """Accumulates the discriminator's parameter gradients; returns dL/d feat (N,T,256) already multiplied by
+        -grl_coeff (the gradient-reverse layer)."""
+        N = ctx["N"]
+        lay = ctx["layers"]
+        dense = self.P("dense_d")
+        ops.stats_to_grad(ctx["dwl"], 16, 0, dense.weight.grad)
+        ops.stats_to_grad(ctx["dbl"], 1, 0, dense.bias.grad)
+        g, stats = ctx["g5"], ctx["stats5"]
+        for k in range(5, 0, -1):
+            l = lay[k - 1]
+            co, cin = D_CH[k], D_CH[k - 1]
+            bn = self.P(f"bn_{k}")
+            ops.bn_bwd(stats, co, float(l["M"]), bn.weight, l["mean"], l["invstd"], bn.weight.grad, bn.bias.grad, g,
+                       l["y"])
+            dy = g.view(l["M"], co)
+            w = self.P(f"conv_{k}.weight")
+            part, G, KP, NP = ops.wgrad(l["col"], dy, 1, l["M"], 1, l["K"], co)
+            if cin == 1:
+                ops.reduce_partials(part, G, 1, KP, NP, 9, co, w.grad, 0, 1, 9)
+            else:
+                assert KP == 9 * l["CP"]
+                ops.reduce_partials(part, G, 9, l["CP"], NP, cin, co, w.grad, 1, 9, cin * 9)
+            wT, K, cop = self._bwd_weight(k, l["CP"])
+            if cop != co:  # the GEMM contracts over multiples of 16 channels: zero-pad dY of the last layer
+                dyp = torch.zeros((l["M"], cop), device=dy.device, dtype=torch.float32)
+                dyp[:, :co] = dy
+                dy = dyp
+            dcol, _ = ops.igemm(dy, wT, K, 1, l["M"], 1, cop)
+            if k > 1:
+                p = lay[k - 2]
+                g, stats = _col2im(dcol, p["y"], p["scale"], p["shift"], N, l["Hi"], l["Wi"], cin, l["CP"])
+            else:
+                dfeat, _ = _col2im(dcol, None, None, None, N, l["Hi"], l["Wi"], 1, 1, out_scale=-float(grl_coeff))
+        return dfeat.view(N, ctx["T"], ctx["F"])
+
+    def forward(self, x):
+        d, _ = self.run_forward(x, save=False)
+        return d.view(-1, 1)
+
+
+class ConditionalDomainAdversarialLoss(nn.Module):
+    """Same call as the reference: ``loss = cdan(g_s, f_s, g_t, f_t)`` (g_* are accepted and, as in the reference's
+    active code path, do not enter the result).  ``forward`` returns the loss as a device scalar and stores what
+    ``backward_features()`` needs; the explicit pair is what SEDTrainer uses."""
+
+    def __init__(self, domain_discriminator, entropy_conditioning=False, randomized=False, num_classes=-1,
+                 features_dim=-1, randomized_dim=1024, reduction="mean"):
+        super().__init__()
+        if entropy_conditioning or randomized or reduction != "mean":
+            raise NotImplementedError("only the reference's active configuration (plain BCE, mean) is built")
+        self.domain_discriminator = domain_discriminator
+        self.iter_num = 0
+        self.alpha, self.lo, self.hi, self.max_iters = 1.0, 0.0, 1.0, 1000.0
+        self._ctx = None
+
+    def grl_coeff(self):
+        return float(2.0 * (self.hi - self.lo) / (1.0 + np.exp(-self.alpha * self.iter_num / self.max_iters))
+                     - (self.hi - self.lo) + self.lo)
+
+    def forward(self, g_s, f_s, g_t, f_t):
+        coeff = self.grl_coeff()
+        self.iter_num += 1  # auto_step
+        f = torch.cat((f_s.detach(), f_t.detach()), 0)
+        d, ctx = self.domain_discriminator.run_forward(f, n_source=f_s.shape[0], save=True)
+        ctx["coeff"], ctx["ns"] = coeff, f_s.shape[0]
+        self._ctx = ctx
+        self.domain_out = d
+        return ctx["lossp"][:, 0, 0].sum() / f.shape[0]
+
+    def backward_features(self):
+        """(d_f_s, d_f_t) = gradient of the domain loss w.r.t. the features THROUGH the gradient-reverse layer;
+        the discriminator's own parameter gradients are accumulated into its flat_grad."""
+        ctx, self._ctx = self._ctx, None
+        df = self.domain_discriminator.run_backward(ctx, ctx["coeff"])
+        return df[:ctx["ns"]], df[ctx["ns"]:]

@@ -132,7 +132,13 @@ class SEDTrainer:
     reference's ``train_mt`` loop body."""
 
     def __init__(self, crnn, predictor, ema_crnn=None, ema_predictor=None, optimizer=None, frontend=None,
-                 max_consistency_cost=1.0, ema_alpha=0.999, process_group=None, seed=2023):
+                 max_consistency_cost=1.0, ema_alpha=0.999, process_group=None, seed=2023, domain_loss=None,
+                 optimizer_d=None):
+        """domain_loss: a ``disc.ConditionalDomainAdversarialLoss`` (adversarial variant, reference
+        src/main_scmt_ada_weak.py:312-339,527-528,568-574); optimizer_d steps its discriminator."""
+        self.domain_loss, self.optimizer_d = domain_loss, optimizer_d
+        if domain_loss is not None and optimizer_d is None:
+            self.optimizer_d = FlatSGD([domain_loss.domain_discriminator], lr=0.0005 * 0.1)
         self.crnn, self.predictor = crnn, predictor
         self.ema_crnn, self.ema_predictor = ema_crnn, ema_predictor
         self.optimizer = optimizer or FlatAdam([crnn, predictor], lr=0.0005)
@@ -165,7 +171,10 @@ class SEDTrainer:
     def _all_reduce_grads(self):
         if self.world == 1:
             return
-        parallel.all_reduce_flat([self.crnn.flat_grad, self.predictor.flat_grad], self.pg)
+        bufs = [self.crnn.flat_grad, self.predictor.flat_grad]
+        if self.domain_loss is not None:
+            bufs.append(self.domain_loss.domain_discriminator.flat_grad)
+        parallel.all_reduce_flat(bufs, self.pg)
 
     def train_step(self, syn_x, syn_y, real_x=None, real_y_weak=None, real_x_ema=None, consistency_cost=None,
                    from_wave=False):
@@ -187,6 +196,10 @@ class SEDTrainer:
         step_seed = parallel.rank_seed(self.seed, self.global_step, self.rank)
         crnn.train(); pred.train()
         self.optimizer.zero_grad()
+        adv = self.domain_loss is not None and real_x is not None
+        if adv:
+            self.domain_loss.domain_discriminator.train()
+            self.optimizer_d.zero_grad()
         out = {}
         B, Tp, C = syn_y.shape
         # ---- student on the synthetic batch: strong + weak BCE
@@ -195,13 +208,23 @@ class SEDTrainer:
         saved_s = pred.run_forward(enc_s)
         y_weak_syn = syn_y.max(-2)[0].contiguous()
         dx, lp = pred.run_backward(enc_s, saved_s, y_strong=syn_y.contiguous(), y_weak=y_weak_syn)
-        crnn.run_backward(ctx_s, dx)
         out["syn"] = lp
+        dft = None
+        if adv:
+            # domain loss on the SAME encodings (the reference runs a second, numerically identical forward when
+            # dropout is 0 -- SURVEY.md 8d); its feature gradients arrive through the gradient-reverse layer
+            crnn.set_seed(step_seed * 4 + 1)
+            enc_r, ctx_r = crnn.run_forward(real_x, save=True)
+            out["domain"] = self.domain_loss(None, enc_s, None, enc_r)
+            dfs, dft = self.domain_loss.backward_features()
+            ops.axpy(dx, dfs)
+        crnn.run_backward(ctx_s, dx)
         del ctx_s
         # ---- student on the real batch (+ EMA teacher on its noisy twin)
         if real_x is not None:
-            crnn.set_seed(step_seed * 4 + 1)
-            enc_r, ctx_r = crnn.run_forward(real_x, save=mt)
+            if not adv:
+                crnn.set_seed(step_seed * 4 + 1)
+                enc_r, ctx_r = crnn.run_forward(real_x, save=mt)
             saved_r = pred.run_forward(enc_r)
             if mt:
                 w = self.max_consistency_cost if consistency_cost is None else consistency_cost
@@ -212,12 +235,19 @@ class SEDTrainer:
                     strong_e, _, weak_e, _ = self.ema_predictor.run_forward(enc_e)
                 dx, lp = pred.run_backward(enc_r, saved_r, y_weak=real_y_weak.contiguous(), ema_strong=strong_e,
                                            ema_weak=weak_e, w_cons_s=w, w_cons_w=w)
+                if dft is not None:
+                    ops.axpy(dx, dft)
                 crnn.run_backward(ctx_r, dx)
                 out["real"] = lp
+                del ctx_r
+            elif dft is not None:
+                crnn.run_backward(ctx_r, dft.contiguous())
                 del ctx_r
         # ---- data-parallel gradient exchange + update
         self._all_reduce_grads()
         self.optimizer.step(grad_scale=1.0 / self.world)
+        if adv:
+            self.optimizer_d.step(grad_scale=1.0 / self.world)
         self.global_step += 1
         if mt:
             update_ema_variables(crnn, self.ema_crnn, self.ema_alpha, self.global_step)
@@ -234,4 +264,6 @@ class SEDTrainer:
         if "real" in out:
             r = out["real"].double().sum(0).cpu()
             loss += float(r[1] / (B * C) + consistency_cost * (r[2] / (B * Tp * C) + r[3] / (B * C)))
+        if "domain" in out:
+            loss += float(out["domain"])
         return loss

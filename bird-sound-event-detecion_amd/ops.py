@@ -340,6 +340,12 @@ def sgd_step(p, g, buf, lr, momentum, weight_decay, first_step, nesterov=True, g
            _i(1 if nesterov else 0), ctypes.c_float(grad_scale), L.stream())
 
 
+def axpy(y, x, a=1.0):
+    """y += a * x in place (contiguous fp32 tensors of equal size)"""
+    L.call("bsed_axpy", L.ptr(y), L.ptr(x.contiguous()), ctypes.c_long(y.numel()), ctypes.c_float(a), L.stream())
+    return y
+
+
 def ema_update(ema, p, alpha):
     L.call("bsed_ema_update", L.ptr(ema), L.ptr(p), ctypes.c_long(p.numel()), ctypes.c_float(alpha), L.stream())
 

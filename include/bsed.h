@@ -182,6 +182,27 @@ int bsed_glu16_bwd(const float* y, const float* scale, const float* shift, const
                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Clip-level domain discriminator glue (csrc/disc.hip); replaces Clip_Discriminator.forward
+ * (src/models/CRNN_GRL.py:16-53), GradientReverseFunction (src/DA/grl.py:12-22) and the BCE of
+ * ConditionalDomainAdversarialLoss.forward (src/DA/cdan_frame.py:89-119).  The 3x3 / stride-2 / pad-0
+ * convolutions run as im2col + bsed_igemm / bsed_wgrad; images are (N, H = time, W = feature, C).
+ * ---------------------------------------------------------------------------------------------- */
+/* col[(n,ho,wo)][(dw*3+dh)*CP + c] = leaky_relu_0.2(act*scale+shift) (identity when scale == NULL);
+ * C == 1 writes 16 columns (9 taps + zeros).  Ho = (Hi-3)/2+1, Wo = (Wi-3)/2+1. */
+int bsed_im2col_s2(const float* act, const float* scale, const float* shift, float* col, int N, int Hi, int Wi,
+                   int C, int CP, void* stream);
+/* adjoint gather.  C > 1: out = d_act * leaky'(y*scale+shift), stats (bsed_col2im_s2_num_blocks, 2, C) =
+ * per-block (sum g, sum g*y) for bsed_bn_bwd.  C == 1: out = d_act * out_scale (GRL: out_scale = -lambda). */
+int bsed_col2im_s2(const float* dcol, const float* y, const float* scale, const float* shift, float* out,
+                   float* stats, int N, int Hi, int Wi, int C, int CP, float out_scale, void* stream);
+int bsed_col2im_s2_num_blocks(int N, int Hi, int Wi, int C);
+/* BN5 + LeakyReLU + AdaptiveAvgPool2d((2,1)) + Linear(16,1) + sigmoid (+ BCE vs label 1 for n < Ns else 0,
+ * mean over N, and the backward to g5 = dL/d(BN5 output) with per-sample partials) */
+int bsed_disc_head(const float* y5, const float* scale, const float* shift, const float* wl, const float* bl, int N,
+                   int Ns, int H5, int W5, int C5, int train, float* d_out, float* g5, float* stats, float* dwl_part,
+                   float* dbl_part, float* loss_part, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Bidirectional GRU recurrence (csrc/gru.hip); replaces nn.GRU of src/models/RNN.py:7-16.
  *   xp    (B,T,768)  x @ [W_ih; W_ih_reverse]^T + b_ih   (from bsed_igemm), [dir*384 + gate*128 + k]
  *   w_hh  (2,384,128), b_hh (2,384)                       gate order r,z,n
@@ -238,6 +259,8 @@ int bsed_sgd_step(float* p, const float* g, float* buf, long n, float lr, float 
 int bsed_ema_update(float* ema, const float* p, long n, float alpha, void* stream);
 int bsed_ema_update_i64(long long* ema, const long long* p, int n, float alpha, void* stream);
 int bsed_scale(float* x, long n, float s, void* stream);
+/* y += a * x  (sums the class-loss and domain-loss gradients at the encoder output) */
+int bsed_axpy(float* y, const float* x, long n, float a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Self tests (used by tests/ only)

@@ -1,0 +1,120 @@
+"""Clip_Discriminator + gradient-reverse + BCE domain loss on the GPU vs the vectors produced by the reference's
+own Clip_Discriminator / ConditionalDomainAdversarialLoss (tests/golden/clipd.npz) and the torch oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import crnn_oracle as co
+from oracle import seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def test_domain_loss_and_gradients_match_reference(golden_dir):
+    from bsed_amd.disc import Clip_Discriminator, ConditionalDomainAdversarialLoss
+    g = np.load(os.path.join(golden_dir, "clipd.npz"))
+    B, T, seed = (int(v) for v in g["meta"])
+    rng = np.random.default_rng(seed)
+    f_s = rng.standard_normal((B, T, 256)).astype(np.float32)
+    f_t = rng.standard_normal((B, T, 256)).astype(np.float32)
+    odisc = co.Clip_Discriminator()
+    seeded.load_seeded(odisc, seed + 1)
+    disc = Clip_Discriminator(input_dim=8192, dropout=0.5)
+    assert set(disc.state_dict().keys()) == set(odisc.state_dict().keys())
+    disc.load_state_dict(odisc.state_dict())
+    disc.train()
+    cdan = ConditionalDomainAdversarialLoss(disc, entropy_conditioning=False, num_classes=20, features_dim=256)
+    fs, ft = torch.from_numpy(f_s).cuda(), torch.from_numpy(f_t).cuda()
+    names = [str(n) for n in g["dnames"]]
+    for it in range(3):
+        disc.zero_grad()
+        loss = cdan(None, fs, None, ft)
+        dfs, dft = cdan.backward_features()
+        assert abs(float(loss) - float(g[f"loss{it}"])) < 2e-5, (it, float(loss), float(g[f"loss{it}"]))
+        ref = g[f"dfs{it}"]
+        got = dfs.cpu().numpy()[:, ::16, ::8]
+        assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-9, it
+        assert abs(float(dfs.norm()) - float(g[f"dfs_norm{it}"])) <= 2e-4 * float(g[f"dfs_norm{it}"]) + 1e-9
+        assert abs(float(dft.norm()) - float(g[f"dft_norm{it}"])) <= 2e-4 * float(g[f"dft_norm{it}"]) + 1e-9
+        norms = np.array([float(disc.P(n).grad.double().norm()) for n in names])
+        keep = np.array([not (n.startswith("conv_") and n.endswith("bias")) for n in names])  # zero grad under BN
+        np.testing.assert_allclose(norms[keep], g[f"dgrad_norms{it}"][keep], rtol=5e-4, atol=1e-8)
+    disc.eval()
+    with torch.no_grad():
+        out = disc(torch.cat([fs, ft]))
+    np.testing.assert_allclose(out.cpu().numpy(), g["eval_out"], atol=2e-5)
+
+
+def test_discriminator_parameter_gradients_vs_oracle():
+    from bsed_amd.disc import Clip_Discriminator
+    seed, B, T = 4, 3, 101
+    rng = np.random.default_rng(seed)
+    f = rng.standard_normal((2 * B, T, 256)).astype(np.float32)
+    odisc = co.Clip_Discriminator()
+    seeded.load_seeded(odisc, seed)
+    odisc.train()
+    x = torch.from_numpy(f).requires_grad_()
+    loss_ref = co.domain_loss(odisc, x[:B], x[B:], 0.37)
+    loss_ref.backward()
+    disc = Clip_Discriminator()
+    disc.load_state_dict({k: v for k, v in odisc.state_dict().items() if "num_batches" not in k or True})
+    disc.nbt.zero_()
+    disc.train(); disc.zero_grad()
+    d, ctx = disc.run_forward(torch.from_numpy(f).cuda(), n_source=B)
+    df = disc.run_backward(ctx, 0.37)
+    loss = float(ctx["lossp"][:, 0, 0].sum() / (2 * B))
+    assert abs(loss - float(loss_ref)) < 2e-5
+    np.testing.assert_allclose(df.cpu().numpy(), x.grad.numpy(), atol=2e-4 * float(x.grad.abs().max()))
+    for k, p in odisc.named_parameters():
+        if k.startswith("conv_") and k.endswith("bias"):
+            continue
+        got, ref = disc.P(k).grad.cpu().double(), p.grad.double()
+        assert float((got - ref).norm()) <= 5e-4 * float(ref.norm()) + 1e-8, k
+
+
+def test_adversarial_train_step_gradients_match_oracle():
+    """class losses + domain loss through GRL in one step (reference src/main_scmt_ada_weak.py:312-345,527-528)"""
+    from bsed_amd.disc import Clip_Discriminator, ConditionalDomainAdversarialLoss
+    from bsed_amd.engine import FlatSGD, SEDTrainer
+    from bsed_amd.models import CRNN, Predictor
+    seed, B, T = 17, 2, 256
+    kw = dict(co.CRNN_KWARGS); kw["dropout"] = 0.0
+    ocrnn, opred, odisc = co.CRNN(**kw), co.Predictor(**co.PREDICTOR_KWARGS), co.Clip_Discriminator()
+    seeded.load_seeded(ocrnn, seed); seeded.load_seeded(opred, seed + 1); seeded.load_seeded(odisc, seed + 2)
+    xs = seeded.db_like_input(seed + 3, B, T); xr = seeded.db_like_input(seed + 4, B, T)
+    y = seeded.strong_targets(seed + 5, B, T // 4)
+    for m in (ocrnn, opred, odisc):
+        m.train()
+    coeff = co.grl_coeff(7)
+    loss_c, outs = co.train_losses(ocrnn, opred, torch.from_numpy(xs), torch.from_numpy(y), torch.from_numpy(xr))
+    loss_d = co.domain_loss(odisc, outs["enc_syn"], outs["enc_real"], coeff)
+    (loss_c + loss_d).backward()
+
+    crnn, pred, disc = CRNN(**kw), Predictor(**co.PREDICTOR_KWARGS), Clip_Discriminator()
+    ocrnn2 = co.CRNN(**kw); seeded.load_seeded(ocrnn2, seed)          # fresh running stats
+    odisc2 = co.Clip_Discriminator(); seeded.load_seeded(odisc2, seed + 2)
+    crnn.load_state_dict(ocrnn2.state_dict()); pred.load_state_dict(opred.state_dict())
+    disc.load_state_dict(odisc2.state_dict())
+    cdan = ConditionalDomainAdversarialLoss(disc)
+    cdan.iter_num = 7
+    # lr = 0 optimizers: the step leaves parameters alone so the gradients can be inspected afterwards
+    tr = SEDTrainer(crnn, pred, optimizer=FlatSGD([crnn, pred], lr=0.0, momentum=0.0, weight_decay=0.0),
+                    domain_loss=cdan, optimizer_d=FlatSGD([disc], lr=0.0, momentum=0.0, weight_decay=0.0))
+    out = tr.train_step(torch.from_numpy(xs).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(xr).cuda())
+    loss = SEDTrainer.loss_value(out)
+    assert abs(loss - float(loss_c + loss_d)) < 3e-5 * abs(loss), (loss, float(loss_c + loss_d))
+    bad = []
+    for mod, omod in ((crnn, ocrnn), (pred, opred), (disc, odisc)):
+        for k, p in omod.named_parameters():
+            key = k.replace("cnn.cnn.", "cnn.", 1)
+            if (".conv" in key or key.startswith("conv_")) and key.endswith("bias"):
+                continue
+            got, ref = mod.P(key).grad.cpu().double(), p.grad.double()
+            err = float((got - ref).norm())
+            # BatchNorm bias gradients are cancellation-heavy sums over ~1e5 positions: fp32 summation order alone
+            # moves them by ~1e-4 absolute, hence the absolute floor
+            if err > 5e-4 * float(ref.norm()) + 2e-4:
+                bad.append((key, err, float(ref.norm())))
+    assert not bad, bad
