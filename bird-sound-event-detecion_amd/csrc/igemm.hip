@@ -139,58 +139,84 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_kernel(const IgemmParams P) 
   const float dscale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
   const int nbase = n0 + li;
 
+  // Side inputs (pre-BN activation, pooled gradient, residual) are fetched for FOUR accumulator rows at a time
+  // before any store: a store to `out` may alias those loads as far as the compiler knows (and does alias for the
+  // in-place residual form), which would otherwise serialise one exposed global-load latency per element.
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int mm = wave * 32 + crow(r, lh);
-    const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
-    const bool pok = gh < p.H && gw < p.W;
-    const size_t pos = ((size_t)nb * p.H + gh) * p.W + gw;
-    float* orow = p.out + pos * p.out_pitch + nbase;
-    const float* erow = p.e_src + pos * p.e_pitch + nbase;
-    const uint64_t ebase = (uint64_t)pos * p.N + nbase;
-    const float* dprow = nullptr;
-    bool pooled_ok = false;
-    if (EPI == EPI_GLU_BWD) {
-      const int gph = gh >> sph, gpw = gw >> spw;
-      pooled_ok = pok && gph < p.Hp && gpw < p.Wp;
-      dprow = p.e_dpool + (((size_t)nb * p.Hp + gph) * p.Wp + gpw) * p.N + nbase;
+  for (int rg = 0; rg < 4; ++rg) {
+    float ev[4][NT], dv[4][NT], rv[4][NT];
+    size_t posv[4];
+    int mmv[4];
+    bool pokv[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = rg * 4 + rr;
+      const int mm = wave * 32 + crow(r, lh);
+      const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
+      const bool pok = gh < p.H && gw < p.W;
+      const size_t pos = ((size_t)nb * p.H + gh) * p.W + gw;
+      mmv[rr] = mm; pokv[rr] = pok; posv[rr] = pos;
+      bool pooled_ok = false;
+      const float* dprow = nullptr;
+      if (EPI == EPI_GLU_BWD) {
+        const int gph = gh >> sph, gpw = gw >> spw;
+        pooled_ok = pok && gph < p.Hp && gpw < p.Wp;
+        dprow = p.e_dpool + (((size_t)nb * p.Hp + gph) * p.Wp + gpw) * p.N + nbase;
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const bool ok = pok && nok[j];
+        ev[rr][j] = 0.f; dv[rr][j] = 0.f; rv[rr][j] = 0.f;
+        if (EPI == EPI_GLU_POOL || EPI == EPI_GLU_BWD || EPI == EPI_ADD_STATS2)
+          if (ok) ev[rr][j] = p.e_src[pos * p.e_pitch + nbase + 32 * j];
+        if (EPI == EPI_GLU_BWD)
+          if (pooled_ok && nok[j]) dv[rr][j] = dprow[32 * j];
+        if (EPI == EPI_ADD_STATS2)
+          if (ok) rv[rr][j] = p.out2[pos * p.out_pitch + nbase + 32 * j];
+      }
     }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const bool ok = pok && nok[j];
-      const float v = acc[j][r] + bias[j];
-      if (EPI == EPI_PLAIN) {
-        if (ok) orow[32 * j] = v;
-      } else if (EPI == EPI_STATS) {
-        if (ok) {
-          orow[32 * j] = v;
-          s0[j] += v;
-          s1[j] = fmaf(v, v, s1[j]);
-        }
-      } else if (EPI == EPI_GLU_POOL) {
-        float res = 0.f;
-        if (ok) {
-          const float xn = fmaf(erow[32 * j], esc[j], esh[j]);
-          res = v * sigmoid_fast(xn) * drop_mul(ebase + 32 * j, dkey, dthr, dscale);
-        }
-        Cs[mm * (BN + 1) + 32 * j + li] = res;
-      } else if (EPI == EPI_GLU_BWD) {
-        if (ok) {
-          const float xn = fmaf(erow[32 * j], esc[j], esh[j]);
-          const float sg = sigmoid_fast(xn);
-          float dres = 0.f;
-          if (pooled_ok) dres = dprow[32 * j] * inv_pool * drop_mul(ebase + 32 * j, dkey, dthr, dscale);
-          const float dlin = dres * sg;
-          orow[32 * j] = dlin;
-          p.out2[pos * p.out_pitch + nbase + 32 * j] = dres * v * sg * (1.0f - sg);
-          s0[j] += dlin;
-        }
-      } else {  // EPI_ADD_STATS2: g = acc + residual ; stats = (sum g, sum g*y)
-        if (ok) {
-          const float g = v + p.out2[pos * p.out_pitch + nbase + 32 * j];
-          orow[32 * j] = g;
-          s0[j] += g;
-          s1[j] = fmaf(g, erow[32 * j], s1[j]);
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = rg * 4 + rr;
+      const size_t pos = posv[rr];
+      float* orow = p.out + pos * p.out_pitch + nbase;
+      const uint64_t ebase = (uint64_t)pos * p.N + nbase;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const bool ok = pokv[rr] && nok[j];
+        const float v = acc[j][r] + bias[j];
+        if (EPI == EPI_PLAIN) {
+          if (ok) orow[32 * j] = v;
+        } else if (EPI == EPI_STATS) {
+          if (ok) {
+            orow[32 * j] = v;
+            s0[j] += v;
+            s1[j] = fmaf(v, v, s1[j]);
+          }
+        } else if (EPI == EPI_GLU_POOL) {
+          float res = 0.f;
+          if (ok) {
+            const float xn = fmaf(ev[rr][j], esc[j], esh[j]);
+            res = v * sigmoid_fast(xn) * drop_mul(ebase + 32 * j, dkey, dthr, dscale);
+          }
+          Cs[mmv[rr] * (BN + 1) + 32 * j + li] = res;
+        } else if (EPI == EPI_GLU_BWD) {
+          if (ok) {
+            const float xn = fmaf(ev[rr][j], esc[j], esh[j]);
+            const float sg = sigmoid_fast(xn);
+            const float dres = dv[rr][j] * inv_pool * drop_mul(ebase + 32 * j, dkey, dthr, dscale);
+            const float dlin = dres * sg;
+            orow[32 * j] = dlin;
+            p.out2[pos * p.out_pitch + nbase + 32 * j] = dres * v * sg * (1.0f - sg);
+            s0[j] += dlin;
+          }
+        } else {  // EPI_ADD_STATS2: g = acc + residual ; stats = (sum g, sum g*y)
+          if (ok) {
+            const float g = v + rv[rr][j];
+            orow[32 * j] = g;
+            s0[j] += g;
+            s1[j] = fmaf(g, ev[rr][j], s1[j]);
+          }
         }
       }
     }
