@@ -134,6 +134,7 @@ class CRNN(_FlatModule):
         self.nb_filters, self.pooling, self.dropout_p = nb_filters, pooling, float(dropout)
         self.n_hidden = n_RNN_cell
         self.seed = 0
+        self.fused_glu_bwd = True  # False = the unfused 4-launch chain (kept as a cross-check in the tests)
         pspecs, bspecs = [], []
         cin = 1
         for i, co in enumerate(nb_filters):
@@ -317,6 +318,14 @@ class CRNN(_FlatModule):
                 g, pdw, pdb, st2, G = ops.glu16_bwd(y, blk["scale"], blk["shift"], glu.weight, glu.bias,
                                                     dpool.contiguous(), B, Hh, Ww, (ph, pw), drop_b, 100 + i, seed)
                 ops.reduce_partials(pdw, G, 1, 16, 16, 16, 16, glu.weight.grad, 0, 16, 1)
+                ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
+            elif co in (32, 64, 128) and self.fused_glu_bwd:
+                # three chained MFMA contractions per tile, y read once, g written once (csrc/glu_bwd.hip)
+                wfwd = ops.pack_weight(glu.weight, 1, co, co, 0, 1, co)
+                g, pdw, pdb, st2, G, slabs = ops.glu_bwd_fused(y, blk["scale"], blk["shift"], wfwd, glu.weight,
+                                                               glu.bias, dpool.contiguous(), B, Hh, Ww, co, (ph, pw),
+                                                               drop_b, 100 + i, seed)
+                ops.reduce_partials(pdw, G * slabs, 1, co, co, co, co, glu.weight.grad, 0, co, 1)
                 ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
             else:
                 # (1) recompute lin, form d_lin and the gate-branch term

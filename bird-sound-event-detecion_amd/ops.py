@@ -232,6 +232,27 @@ def glu16_bwd(y, scale, shift, wg, bg, dpool, B, H, W, pool, drop_p, rng_stream,
     return g, part_dw, part_db, part_st, G
 
 
+def glu_bwd_fused(y, scale, shift, wfwd, w, bias, dpool, B, H, W, C, pool, drop_p, rng_stream, seed):
+    """returns (g, part_dw (G*slabs,C,C), part_db (G,2,C), part_st (G,2,C), G, slabs)"""
+    ph, pw = pool
+    dev = y.device
+    TH, TW = tile_for(W)
+    ntiles = B * ((H + TH - 1) // TH) * (W // TW)
+    G = int(min(ntiles, 256 * (1 if C == 128 else (2 if C == 64 else 3))))
+    slabs = L.lib().bsed_glu_bwd_slabs(C)
+    g = torch.empty_like(y)
+    part_dw = torch.empty((G * slabs, C, C), device=dev, dtype=torch.float32)
+    part_db = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
+    part_st = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
+    flops = 3 * 2.0 * B * H * W * C * C
+    _launch(("glu_bwd_fused", 0, 1, C, C, H, W), flops,
+            lambda: L.call("bsed_glu_bwd_fused", L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(wfwd), _fp(_dp(w)),
+                           _fp(_dp(bias)), L.ptr(dpool), L.ptr(g), L.ptr(part_dw), L.ptr(part_db), L.ptr(part_st),
+                           _i(G), _i(B), _i(H), _i(W), _i(C), _i(TH), _i(TW), _i(ph), _i(pw), ctypes.c_float(drop_p),
+                           ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream()))
+    return g, part_dw, part_db, part_st, G, slabs
+
+
 def bn_finalize(stats, C, count, eps, momentum, gamma, beta, rmean, rvar, nbt):
     dev = stats.device
     mean, invstd, scale, shift = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(4))

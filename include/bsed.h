@@ -181,6 +181,16 @@ int bsed_glu16_bwd(const float* y, const float* scale, const float* shift, const
                    int H, int W, int C, int ph, int pw, float drop_p, uint32_t rng_stream, uint64_t seed,
                    void* stream);
 
+/* Fused GLU backward for C in {32,64,128} (csrc/glu_bwd.hip): y, d_pooled -> g = dL/d(BN output) in one pass, with
+ * the three contractions (lin recompute, g, dW) chained on chip.  wfwd = bsed_pack_weight'ed W^T ([c][n]),
+ * wbwd = the (C,C) Linear weight itself.  Outputs per-workgroup partials: part_dw (G*bsed_glu_bwd_slabs(C), C, C),
+ * part_db (G,2,C) [slot 0 = sum d_lin], part_st (G,2,C) = (sum g, sum g*y) for bsed_bn_bwd. */
+int bsed_glu_bwd_fused(const float* y, const float* scale, const float* shift, const float* wfwd,
+                       const float* wbwd, const float* bias, const float* dpool, float* g, float* part_dw,
+                       float* part_db, float* part_st, int G, int NB, int H, int W, int C, int TH, int TW, int ph,
+                       int pw, float drop_p, uint32_t rng_stream, uint64_t seed, void* stream);
+int bsed_glu_bwd_slabs(int C);
+
 /* ------------------------------------------------------------------------------------------------
  * Clip-level domain discriminator glue (csrc/disc.hip); replaces Clip_Discriminator.forward
  * (src/models/CRNN_GRL.py:16-53), GradientReverseFunction (src/DA/grl.py:12-22) and the BCE of

@@ -298,3 +298,23 @@ def test_train_step_from_waveforms_runs_mel_on_gpu():
     l1 = SEDTrainer.loss_value(out)
     assert np.isfinite(l0) and np.isfinite(l1) and l1 < l0
     assert not torch.equal(before, crnn.flat)
+
+
+def test_fused_glu_backward_matches_unfused_chain():
+    """csrc/glu_bwd.hip (one pass, three chained contractions) vs the four-launch chain, dropout ON so the
+    regenerated masks are exercised too"""
+    seed, B, T = 21, 3, 128
+    x = torch.from_numpy(seeded.db_like_input(seed, B, T)).cuda()
+    ocrnn, opred = _oracle(0.5, seed)
+    grads = []
+    for fused in (True, False):
+        crnn, _ = _mine(0.5, ocrnn, opred)
+        crnn.fused_glu_bwd = fused
+        crnn.train(); crnn.set_seed(77)
+        enc, ctx = crnn.run_forward(x, save=True)
+        d_enc = torch.sin(torch.arange(enc.numel(), device="cuda", dtype=torch.float32)).view_as(enc) * 1e-2
+        crnn.zero_grad()
+        crnn.run_backward(ctx, d_enc)
+        grads.append(crnn.flat_grad.clone())
+    err = float((grads[0] - grads[1]).norm() / grads[1].norm())
+    assert err < 2e-5, err
