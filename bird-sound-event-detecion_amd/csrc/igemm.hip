@@ -611,7 +611,9 @@ extern "C" int bsed_wgrad_auto_g(const BsedWgradDesc* desc) {
   size_t smem;
   dim3 gyz;
   if (wgrad_prepare(desc, P, smem, gyz) != BSED_OK) return -1;
-  const long want = ceil_div(768, (long)gyz.y * gyz.z);
+  // exactly one resident round of workgroups (2 per CU when two tiles fit in LDS): no partial tail round
+  const long slots = smem <= 80 * 1024 ? 512 : 256;
+  const long want = std::max<long>(1, slots / ((long)gyz.y * gyz.z));
   return (int)std::max<long>(1, std::min<long>(want, P.ntiles));
 }
 
