@@ -114,11 +114,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
+    ngpu = torch.cuda.device_count()
+    # one process per GPU; BSED_DIST_BACKEND=gloo lets several ranks share one card for rehearsals of the N>1 path
+    backend = os.environ.get("BSED_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(ngpu, 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if "RANK" in os.environ:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
 
     from bsed_amd import ops
     from bsed_amd.engine import FlatAdam, SEDTrainer
@@ -179,7 +186,7 @@ def main():
         elapsed = float(tmax)
     loss = SEDTrainer.loss_value(out)
     if rank != 0:
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
 
@@ -226,7 +233,7 @@ def main():
     }
     line.update(kernels)
     print(json.dumps(line))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -39,10 +39,11 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
   constexpr int NT = C / 32;
   constexpr int XP = C + 1;
   constexpr int KSPLIT = NT >= 4 ? 1 : 4 / NT;  // waves that share one dW row-tile split the positions
+  constexpr bool RES = C <= 32;                  // both weight matrices stay resident in LDS: no slab traffic / barriers
   extern __shared__ __align__(16) float smem[];
   float* Xs = smem;                 // [128][XP]  BatchNorm output
   float* Ds = Xs + GB_M * XP;       // [128][XP]  d_lin
-  float* Bs = Ds + GB_M * XP;       // [32][C]    weight slab
+  float* Bs = Ds + GB_M * XP;       // [32][C]    weight slab   (RES: [2][C][C] = W^T then W, loaded once)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int m = wave * 32 + li;
   const int sph = P.ph >> 1, spw = P.pw >> 1;
@@ -61,6 +62,12 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
   }
   const int nt3 = wave % NT, kq = wave / NT;     // GEMM3 role of this wave
   constexpr int KR = GB_M / KSPLIT;
+  if (RES) {
+    for (int e = tid; e < C * C / 4; e += GB_THREADS) {
+      reinterpret_cast<float4*>(Bs)[e] = reinterpret_cast<const float4*>(P.wfwd)[e];
+      reinterpret_cast<float4*>(Bs + C * C)[e] = reinterpret_cast<const float4*>(P.wbwd)[e];
+    }
+  }
 
   for (int tile0 = blockIdx.x; tile0 < P.ntiles; tile0 += gridDim.x) {
     int tile = tile0;
@@ -104,15 +111,18 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     // ---- GEMM1: lin = xn W^T
+    if (RES) __syncthreads();  // staged tile (and, first time, the resident weights) visible
     for (int k0 = 0; k0 < C; k0 += 32) {
-      __syncthreads();
-      for (int e = tid; e < 32 * C4; e += GB_THREADS) {
-        const int k = e / C4, n4 = e % C4;
-        *reinterpret_cast<float4*>(Bs + k * C + 4 * n4) = *reinterpret_cast<const float4*>(P.wfwd + (size_t)(k0 + k) * C + 4 * n4);
+      if (!RES) {
+        __syncthreads();
+        for (int e = tid; e < 32 * C4; e += GB_THREADS) {
+          const int k = e / C4, n4 = e % C4;
+          *reinterpret_cast<float4*>(Bs + k * C + 4 * n4) = *reinterpret_cast<const float4*>(P.wfwd + (size_t)(k0 + k) * C + 4 * n4);
+        }
+        __syncthreads();
       }
-      __syncthreads();
       const float* arow = Xs + m * XP + k0 + lh;
-      const float* brow = Bs + lh * C + li;
+      const float* brow = (RES ? Bs + k0 * C : Bs) + lh * C + li;
 #pragma unroll 4
       for (int kk = 0; kk < 32; kk += 2) {
         const float a = arow[kk];
@@ -163,16 +173,18 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
       }
     }
 
-    // ---- GEMM2: g = d_lin W + gate term (already in acc)
+    // ---- GEMM2: g = d_lin W + gate term (already in acc); its A rows are this wave's own d_lin rows
     for (int k0 = 0; k0 < C; k0 += 32) {
-      __syncthreads();
-      for (int e = tid; e < 32 * C4; e += GB_THREADS) {
-        const int k = e / C4, n4 = e % C4;
-        *reinterpret_cast<float4*>(Bs + k * C + 4 * n4) = *reinterpret_cast<const float4*>(P.wbwd + (size_t)(k0 + k) * C + 4 * n4);
+      if (!RES) {
+        __syncthreads();
+        for (int e = tid; e < 32 * C4; e += GB_THREADS) {
+          const int k = e / C4, n4 = e % C4;
+          *reinterpret_cast<float4*>(Bs + k * C + 4 * n4) = *reinterpret_cast<const float4*>(P.wbwd + (size_t)(k0 + k) * C + 4 * n4);
+        }
+        __syncthreads();
       }
-      __syncthreads();
       const float* arow = Ds + m * XP + k0 + lh;
-      const float* brow = Bs + lh * C + li;
+      const float* brow = (RES ? Bs + C * C + k0 * C : Bs) + lh * C + li;
 #pragma unroll 4
       for (int kk = 0; kk < 32; kk += 2) {
         const float a = arow[kk];
@@ -211,7 +223,8 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
       }
     }
 
-    // ---- GEMM3: dW[n][c] += sum_p d_lin[p][n] xn[p][c]   (Ds/Xs complete since the GEMM2 barriers)
+    // ---- GEMM3: dW[n][c] += sum_p d_lin[p][n] xn[p][c]   (needs every wave's d_lin rows)
+    if (RES) __syncthreads();
     {
       const float* abase = Ds + nt3 * 32 + li;
       const float* bbase = Xs + li;
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
 
 template <int C>
 static int launch_glu_bwd(const GluBwdParams& P, int G, hipStream_t s) {
-  const size_t smem = ((size_t)2 * GB_M * (C + 1) + 32 * C) * sizeof(float);
+  const size_t smem = ((size_t)2 * GB_M * (C + 1) + (C <= 32 ? 2 * C * C : 32 * C)) * sizeof(float);
   static bool done = false;
   if (!done) {
     BSED_HIP(hipFuncSetAttribute((const void*)glu_bwd_fused_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -274,6 +274,7 @@ struct WgradParams {
   BsedWgradDesc d;
   int PW, PH, PP, lgTW, dy_off, ntiles, nct, ntw;  // nct = CC/32, ntw = 32-wide dy tiles per workgroup
   int CC, lgc4, pw_magic;                          // input-channel chunk per workgroup (grid.z), log2(CC/4)
+  int pack2;                                       // CIN <= 16: two taps share one 32-row MFMA tile
 };
 
 // NW waves per workgroup share one staged (activation patch, dy tile) pair: 8 waves double the resident waves per
@@ -291,7 +292,8 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(const WgradParams P) {
   const int DYW = 32 * P.ntw;
   const int n0 = blockIdx.y * DYW;
   const int PW = P.PW;
-  const int nitems = p.ntaps * P.nct * P.ntw;
+  const int ntap_items = P.pack2 ? (p.ntaps + 1) / 2 : p.ntaps;
+  const int nitems = ntap_items * P.nct * P.ntw;
 
   int xoff[MAXS], boff[MAXS];
   bool valid[MAXS];
@@ -303,7 +305,15 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(const WgradParams P) {
     // item -> (input-channel tile, dy tile, tap); a wave's items share the channel tile when ntw == 4
     const int cit = valid[s] ? it % P.nct : 0, rr = valid[s] ? it / P.nct : 0;
     const int nt = rr % P.ntw, tap = rr / P.ntw;
-    xoff[s] = (p.dh[tap] * PW + p.dw[tap]) * XP + cit * 32 + li;
+    if (P.pack2) {
+      // rows 0..15 of the tile: tap 2*tap, rows 16..31: tap 2*tap+1 (channels 16..31 of the staged patch are zero,
+      // which is what the upper rows read when the second tap does not exist)
+      const int ta = 2 * tap, tb = 2 * tap + 1;
+      if (li < 16 || tb >= p.ntaps) xoff[s] = (p.dh[ta] * PW + p.dw[ta]) * XP + li;
+      else xoff[s] = (p.dh[tb] * PW + p.dw[tb]) * XP + (li - 16);
+    } else {
+      xoff[s] = (p.dh[tap] * PW + p.dw[tap]) * XP + cit * 32 + li;
+    }
     boff[s] = nt * 32 + li;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
@@ -398,8 +408,14 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(const WgradParams P) {
       const int nt = rr % P.ntw, tap = rr / P.ntw;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int ci = cz0 + cit * 32 + crow(r, lh);
-        p.part[(((size_t)blockIdx.x * p.ntaps + tap) * p.CINP + ci) * NPo + n0 + nt * 32 + li] = acc[s][r];
+        int ci = cz0 + cit * 32 + crow(r, lh), tp = tap;
+        if (P.pack2) {
+          const int row = crow(r, lh);
+          tp = 2 * tap + (row >> 4);
+          ci = row & 15;
+          if (tp >= p.ntaps) continue;
+        }
+        p.part[(((size_t)blockIdx.x * p.ntaps + tp) * p.CINP + ci) * NPo + n0 + nt * 32 + li] = acc[s][r];
       }
     }
   }
@@ -585,6 +601,7 @@ static int wgrad_prepare(const BsedWgradDesc* desc, WgradParams& P, size_t& smem
   BSED_CHECK_ARG(d.CINP % P.CC == 0 && d.CINP / P.CC <= 65535, "bsed_wgrad: CINP must be a multiple of 32");
   P.lgc4 = ilog2_exact(P.CC / 4);
   P.nct = P.CC / 32;
+  P.pack2 = (d.CIN <= 16 && d.CINP == 32 && d.ntaps > 1) ? 1 : 0;
   P.dy_off = (P.PP * (P.CC + 1) + 3) & ~3;
   P.pw_magic = ((1 << 20) + P.PW - 1) / P.PW;
   for (int pos = 0; pos < P.PP; ++pos)
@@ -597,7 +614,8 @@ static int wgrad_prepare(const BsedWgradDesc* desc, WgradParams& P, size_t& smem
   for (int cand = 4; cand >= 2; cand >>= 1) {
     const size_t need = ((size_t)P.dy_off + IG_TILE_M * 32 * cand) * sizeof(float);
     const size_t budget = d.ntaps == 1 ? 160 * 1024 : 80 * 1024;
-    if (d.NP % (32 * cand) == 0 && d.ntaps * P.nct * cand <= 36 && need <= budget) { P.ntw = cand; break; }
+    const int tap_items = P.pack2 ? (d.ntaps + 1) / 2 : d.ntaps;
+    if (d.NP % (32 * cand) == 0 && tap_items * P.nct * cand <= 36 && need <= budget) { P.ntw = cand; break; }
   }
   smem = ((size_t)P.dy_off + IG_TILE_M * 32 * P.ntw) * sizeof(float);
   BSED_CHECK_ARG(smem <= 160 * 1024, "bsed_wgrad: tile needs %zu B of LDS", smem);
@@ -629,7 +647,7 @@ extern "C" int bsed_wgrad(const BsedWgradDesc* desc, void* stream) {
   BsedWgradDesc& d = P.d;
   BSED_CHECK_ARG(d.in && d.dy && d.part, "bsed_wgrad: null tensor");
   BSED_CHECK_ARG(d.G > 0 && d.G <= P.ntiles, "bsed_wgrad: G (%d) must be in 1..%d tiles", d.G, P.ntiles);
-  const int nitems = d.ntaps * P.nct * P.ntw;
+  const int nitems = (P.pack2 ? (d.ntaps + 1) / 2 : d.ntaps) * P.nct * P.ntw;
   dim3 grid((unsigned)d.G, gyz.y, gyz.z);
   hipStream_t s = (hipStream_t)stream;
   if (nitems >= 16 && d.ntaps == 1) {  // 1-tap forms: 8 waves per staged tile (measured +55 %); 9-tap forms are faster with 4
