@@ -638,6 +638,29 @@ extern "C" int bsed_wgrad_auto_g(const BsedWgradDesc* desc) {
   return (int)std::max<long>(1, std::min<long>(want, P.ntiles));
 }
 
+// which template instance bsed_wgrad will launch for this shape: MAXS * 16 + NW (profiling / bench labels)
+static int wgrad_variant(const WgradParams& P) {
+  const BsedWgradDesc& d = P.d;
+  const int nitems = (P.pack2 ? (d.ntaps + 1) / 2 : d.ntaps) * P.nct * P.ntw;
+  if (nitems >= 16 && d.ntaps == 1) {
+    const int slots8 = ceil_div(nitems, 8);
+    if (slots8 <= 2) return 2 * 16 + 8;
+    if (slots8 <= 3) return 3 * 16 + 8;
+    if (slots8 <= 5) return 5 * 16 + 8;
+  }
+  const int slots = ceil_div(nitems, 4);
+  const int m = slots <= 1 ? 1 : slots <= 2 ? 2 : slots <= 3 ? 3 : slots <= 5 ? 5 : 9;
+  return m * 16 + 4;
+}
+
+extern "C" int bsed_wgrad_variant(const BsedWgradDesc* desc) {
+  WgradParams P;
+  size_t smem;
+  dim3 gyz;
+  if (wgrad_prepare(desc, P, smem, gyz) != BSED_OK) return -1;
+  return wgrad_variant(P);
+}
+
 extern "C" int bsed_wgrad(const BsedWgradDesc* desc, void* stream) {
   WgradParams P;
   size_t smem;

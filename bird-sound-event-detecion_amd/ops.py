@@ -139,7 +139,9 @@ def igemm(inp, wpk, N, NB, H, W, CIN, taps=((0, 0),), bias=None, out=None, epilo
     d.ph, d.pw, d.Hp, d.Wp = ph, pw, Hp, Wp
     d.epilogue = epilogue
     d.drop_p, d.rng_stream, d.seed = drop_p, rng_stream, seed
-    _launch(("igemm", epilogue, len(taps), CIN, N, H, W), 2.0 * NB * H * W * len(taps) * CIN * N,
+    kc = 32 if CIN % 32 == 0 else 16
+    bn = 128 if NP % 128 == 0 else (64 if NP % 64 == 0 else 32)
+    _launch((f"igemm_kernel<{kc}, {bn}, {epilogue}>", len(taps), CIN, N, H, W), 2.0 * NB * H * W * len(taps) * CIN * N,
             lambda: L.call("bsed_igemm", ctypes.byref(d), L.stream()))
     return out, stats
 
@@ -166,7 +168,8 @@ def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=Non
         raise L.BsedError("bsed_wgrad_auto_g: " + L.lib().bsed_last_error().decode())
     part = torch.empty((G, len(taps), CINP, NP), device=inp.device, dtype=torch.float32)
     d.part, d.G = _p(part), G
-    _launch(("wgrad", 0, len(taps), CIN, N, H, W), 2.0 * NB * H * W * len(taps) * CIN * N,
+    var = L.lib().bsed_wgrad_variant(ctypes.byref(d))
+    _launch((f"wgrad_kernel<{var // 16}, {var % 16}>", len(taps), CIN, N, H, W), 2.0 * NB * H * W * len(taps) * CIN * N,
             lambda: L.call("bsed_wgrad", ctypes.byref(d), L.stream()))
     return part, G, CINP, NP
 
@@ -245,7 +248,7 @@ def glu_bwd_fused(y, scale, shift, wfwd, w, bias, dpool, B, H, W, C, pool, drop_
     part_db = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
     part_st = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
     flops = 3 * 2.0 * B * H * W * C * C
-    _launch(("glu_bwd_fused", 0, 1, C, C, H, W), flops,
+    _launch((f"glu_bwd_fused_kernel<{C}>", 1, C, C, H, W), flops,
             lambda: L.call("bsed_glu_bwd_fused", L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(wfwd), _fp(_dp(w)),
                            _fp(_dp(bias)), L.ptr(dpool), L.ptr(g), L.ptr(part_dw), L.ptr(part_db), L.ptr(part_st),
                            _i(G), _i(B), _i(H), _i(W), _i(C), _i(TH), _i(TW), _i(ph), _i(pw), ctypes.c_float(drop_p),

@@ -124,6 +124,8 @@ typedef struct BsedWgradDesc {
 int bsed_wgrad(const BsedWgradDesc* desc /*host*/, void* stream);
 /* recommended number of partial slabs G for this shape (pointers in desc are ignored) */
 int bsed_wgrad_auto_g(const BsedWgradDesc* desc /*host*/);
+/* template instance bsed_wgrad launches for this shape, as MAXS*16 + NW (labels profiles and bench lines) */
+int bsed_wgrad_variant(const BsedWgradDesc* desc /*host*/);
 /* dst[tap*s_tap + k*s_k + n*s_n] (+)= sum_g part[g][tap][k][n]   (k < K, n < N) */
 int bsed_reduce_partials(const float* part, int G, int ntaps, int KP, int NP, int K, int N, float* dst,
                          long s_tap, long s_k, long s_n, int accumulate, void* stream);
