@@ -103,8 +103,9 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ strong,
     const float* __restrict__ sof_raw, const float* __restrict__ weak, const float* __restrict__ den,
     const float* __restrict__ y_strong, const float* __restrict__ y_weak, const float* __restrict__ ema_strong,
-    const float* __restrict__ ema_weak, const float* __restrict__ g_strong_ext, const float* __restrict__ g_weak_ext,
-    float w_strong, float w_weak, float w_cons_s, float w_cons_w, float inv_n_strong, float inv_n_weak,
+    const float* __restrict__ ema_weak, const float* __restrict__ ema_strong2, const float* __restrict__ g_strong_ext,
+    const float* __restrict__ g_weak_ext, float w_strong, float w_weak, float w_cons_s, float w_cons_w,
+    float w_cons_s2, float inv_n_strong, float inv_n_weak,
     float* __restrict__ dx, float* __restrict__ dw_part /*(B,2C,256)*/, float* __restrict__ db_part /*(B,2C)*/,
     float* __restrict__ loss_part /*(B,4)*/, int T, int attention) {
   extern __shared__ __align__(16) float smem[];
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_kernel(
   float* lred = dn + C;                      // [HD_THREADS]
   const int tid = threadIdx.x, b_ = blockIdx.x;
   for (int i = tid; i < 2 * C * HD_K; i += HD_THREADS) ws[(i / HD_K) * (HD_K + 1) + (i % HD_K)] = w[i];
-  float l_s = 0.f, l_w = 0.f, l_cs = 0.f, l_cw = 0.f;
+  float l_s = 0.f, l_w = 0.f, l_cs = 0.f, l_cw = 0.f, l_cs2 = 0.f;
   if (tid < C) {
     const float wv = weak[(size_t)b_ * C + tid];
     float g = 0.f;
@@ -169,6 +170,11 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_kernel(
             gs += w_cons_s * 2.f * d * inv_n_strong;
             l_cs += d * d;
           }
+          if (ema_strong2) {
+            const float d = s - ema_strong2[o + c];
+            gs += w_cons_s2 * 2.f * d * inv_n_strong;
+            l_cs2 += d * d;
+          }
           if (g_strong_ext) gs += g_strong_ext[o + c];
           dls = gs * s * (1.f - s);
           if (attention && p >= 1e-7f && p <= 1.0f) ga[c] = gwk[c] * (s - wk[c]) / dn[c];
@@ -207,15 +213,15 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_kernel(
   for (int c = 0; c < 2 * C; ++c) dw_part[((size_t)b_ * 2 * C + c) * HD_K + tid] = dwacc[c];
   if (tid < 2 * C) db_part[(size_t)b_ * 2 * C + tid] = dbacc;
   // loss partials of this clip (plain sums; the host applies weights and 1/N)
-  float vals[4] = {l_s, l_w, l_cs, l_cw};
-  for (int i = 0; i < 4; ++i) {
+  float vals[6] = {l_s, l_w, l_cs, l_cw, l_cs2, 0.f};
+  for (int i = 0; i < 6; ++i) {
     __syncthreads();
     lred[tid] = vals[i];
     __syncthreads();
     if (tid == 0) {
       float s = 0.f;
       for (int j = 0; j < HD_THREADS; ++j) s += lred[j];
-      loss_part[(size_t)b_ * 4 + i] = s;
+      loss_part[(size_t)b_ * 6 + i] = s;
     }
   }
 }
@@ -251,8 +257,9 @@ extern "C" int bsed_head_bwd(const BsedHeadBwdDesc* d, void* stream) {
   }
   hipLaunchKernelGGL(head_bwd_kernel<20>, dim3(d->B), dim3(HD_THREADS), smem, (hipStream_t)stream, d->x, d->w,
                      d->strong, d->sof_raw, d->weak, d->den, d->y_strong, d->y_weak, d->ema_strong, d->ema_weak,
-                     d->g_strong_ext, d->g_weak_ext, d->w_strong, d->w_weak, d->w_cons_s, d->w_cons_w, d->inv_n_strong,
-                     d->inv_n_weak, d->dx, d->dw_part, d->db_part, d->loss_part, d->T, d->attention);
+                     d->ema_strong2, d->g_strong_ext, d->g_weak_ext, d->w_strong, d->w_weak, d->w_cons_s, d->w_cons_w,
+                     d->w_cons_s2, d->inv_n_strong, d->inv_n_weak, d->dx, d->dw_part, d->db_part, d->loss_part, d->T,
+                     d->attention);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }

@@ -58,6 +58,20 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = fmaf(a, x[i], y[i]);
 }
 
+__global__ void roll_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+                            const int* __restrict__ sh, const int* __restrict__ sw) {
+  const long per = (long)H * W, total = per * B;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per);
+    const long r = i - (long)b * per;
+    const int h = (int)(r / W), w = (int)(r % W);
+    int hs = sh ? (h - sh[b]) % H : h, ws = sw ? (w - sw[b]) % W : w;
+    if (hs < 0) hs += H;
+    if (ws < 0) ws += W;
+    out[i] = in[(long)b * per + (long)hs * W + ws];
+  }
+}
+
 static inline unsigned flat_grid(long n) { return (unsigned)std::min<long>(std::max<long>(ceil_div(n, 256), 1), 4096); }
 
 extern "C" int bsed_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
@@ -97,6 +111,13 @@ extern "C" int bsed_ema_update_i64(long long* ema, const long long* p, int n, fl
 extern "C" int bsed_axpy(float* y, const float* x, long n, float a, void* stream) {
   BSED_CHECK_ARG(y && x && n > 0, "bsed_axpy: bad argument");
   hipLaunchKernelGGL(axpy_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, y, x, n, a);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_roll(const float* in, float* out, int B, int H, int W, const int* sh, const int* sw, void* stream) {
+  BSED_CHECK_ARG(in && out && in != out && B > 0 && H > 0 && W > 0, "bsed_roll: bad argument");
+  hipLaunchKernelGGL(roll_kernel, dim3(flat_grid((long)B * H * W)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, sh, sw);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }

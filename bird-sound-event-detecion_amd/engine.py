@@ -255,6 +255,111 @@ class SEDTrainer:
         out["shape"] = (B, Tp, C)
         return out
 
+    # ------------------------------------------------------------------ ISP (shift-consistency) iteration
+    def train_step_isp(self, syn_x, syn_y, real_x, real_y_weak, real_x_ema, shift_frames, shift_bins,
+                       consistency_cost=None, pooling_time_ratio=4):
+        """One iteration of ``train_mt`` with ``-mt -ISP`` (reference src/main_baseline.py:229-277,337-420,431-529):
+        on top of the mean-teacher step, time-rolled and frequency-rolled views of the synthetic and the real batch go
+        through the student (4 extra forward/backward passes) and of the noisy real batch through the teacher (2 extra
+        forwards).  shift_frames[k] (a multiple of pooling_time_ratio) / shift_bins[k] are the per-sample rolls the
+        reference draws with random.randint(-64,64)*4 / random.randint(-4,4); the first half of the real batch is the
+        weakly labelled half (its weak targets enter the frequency-shift class loss).  dB-mel inputs (B,1,T,F)."""
+        if self.ema_crnn is None:
+            raise L.BsedError("ISP needs the EMA teacher (the reference's consistency_cost only exists with -mt)")
+        crnn, pred, ema_c, ema_p = self.crnn, self.predictor, self.ema_crnn, self.ema_predictor
+        cc = self.max_consistency_cost if consistency_cost is None else consistency_cost
+        dev = syn_x.device
+        B, Tp, C = syn_y.shape
+        T, F = syn_x.shape[2], syn_x.shape[3]
+        half = real_y_weak.shape[0] // 2
+        sh = torch.as_tensor(list(shift_frames), dtype=torch.int32, device=dev)
+        sf = torch.as_tensor(list(shift_bins), dtype=torch.int32, device=dev)
+        sp = torch.as_tensor([int(v / pooling_time_ratio) for v in shift_frames], dtype=torch.int32, device=dev)
+        step_seed = parallel.rank_seed(self.seed, self.global_step, self.rank)
+        crnn.train(); pred.train(); ema_c.train(); ema_p.train()
+        self.optimizer.zero_grad()
+        syn_x, real_x, real_x_ema = syn_x.contiguous(), real_x.contiguous(), real_x_ema.contiguous()
+        syn_y = syn_y.contiguous()
+        y_weak_syn = syn_y.max(-2)[0].contiguous()
+        n_s, n_w = B * Tp * C, B * C
+        out = {"shape": (B, Tp, C)}
+
+        def fwd(x, slot):
+            crnn.set_seed(step_seed * 16 + slot)
+            enc, ctx = crnn.run_forward(x, save=True)
+            return enc, pred.run_forward(enc), ctx
+
+        # base passes (identical to the mean-teacher step)
+        enc_s, sv_s, ctx_s = fwd(syn_x, 0)
+        enc_r, sv_r, ctx_r = fwd(real_x, 1)
+        with torch.no_grad():
+            def teacher(x, slot):
+                ema_c.set_seed(step_seed * 16 + slot)
+                e, _ = ema_c.run_forward(x, save=False)
+                st, _, wk, _ = ema_p.run_forward(e)
+                return st, wk
+            strong_e, weak_e = teacher(real_x_ema, 8)
+            strong_e_sh, _ = teacher(ops.roll(real_x_ema, B, T, F, sh=sh), 9)
+            strong_e_fs, _ = teacher(ops.roll(real_x_ema, B, T, F, sw=sf), 10)
+        strong_r_roll = ops.roll(sv_r[0], B, Tp, C, sh=sp)      # detached by construction
+        strong_s_roll = ops.roll(sv_s[0], B, Tp, C, sh=sp)
+        y_s_roll = ops.roll(syn_y, B, Tp, C, sh=sp)
+        dx, out["syn"] = pred.run_backward(enc_s, sv_s, y_strong=syn_y, y_weak=y_weak_syn)
+        crnn.run_backward(ctx_s, dx)
+        dx, out["real"] = pred.run_backward(enc_r, sv_r, y_weak=real_y_weak.contiguous(), ema_strong=strong_e,
+                                            ema_weak=weak_e, w_cons_s=cc, w_cons_w=cc)
+        crnn.run_backward(ctx_r, dx)
+        del ctx_s, ctx_r
+        # real, time shift: 1/2 cc MSE vs teacher(shifted) + cc/2 MSE vs the rolled (detached) base prediction
+        enc, sv, ctx = fwd(ops.roll(real_x, B, T, F, sh=sh), 2)
+        dx, out["real_shift"] = pred.run_backward(enc, sv, ema_strong=strong_e_sh, w_cons_s=0.5 * cc,
+                                                  ema_strong2=strong_r_roll, w_cons_s2=0.5 * cc)
+        crnn.run_backward(ctx, dx)
+        # real, frequency shift: 1/2 cc MSE vs teacher(freq-shifted); weak BCE on the weakly labelled half only
+        enc, sv, ctx = fwd(ops.roll(real_x, B, T, F, sw=sf), 3)
+        parts, lps = [], []
+        for lo, hi, yw in ((0, half, real_y_weak[:half].contiguous()), (half, B, None)):
+            if hi <= lo:
+                continue
+            d, lp = pred.run_backward(enc[lo:hi], tuple(t[lo:hi] for t in sv), y_weak=yw, ema_strong=strong_e_fs[lo:hi],
+                                      w_cons_s=0.5 * cc, n_strong=n_s, n_weak=max(half, 1) * C)
+            parts.append(d); lps.append(lp)
+        out["real_fshift_weak_half"], out["real_fshift_rest"] = lps[0], lps[-1]
+        crnn.run_backward(ctx, torch.cat(parts, 0))
+        # synthetic, time shift: strong BCE vs the rolled target + cc/2 MSE vs the rolled (detached) base prediction
+        enc, sv, ctx = fwd(ops.roll(syn_x, B, T, F, sh=sh), 4)
+        dx, out["syn_shift"] = pred.run_backward(enc, sv, y_strong=y_s_roll, ema_strong=strong_s_roll, w_cons_s=0.5 * cc)
+        crnn.run_backward(ctx, dx)
+        # synthetic, frequency shift: strong + weak BCE vs the unshifted targets
+        enc, sv, ctx = fwd(ops.roll(syn_x, B, T, F, sw=sf), 5)
+        dx, out["syn_fshift"] = pred.run_backward(enc, sv, y_strong=syn_y, y_weak=y_weak_syn)
+        crnn.run_backward(ctx, dx)
+        del ctx
+        self._all_reduce_grads()
+        self.optimizer.step(grad_scale=1.0 / self.world)
+        self.global_step += 1
+        update_ema_variables(crnn, ema_c, self.ema_alpha, self.global_step)
+        update_ema_variables(pred, ema_p, self.ema_alpha, self.global_step)
+        out["isp"] = (cc, half)
+        return out
+
+    @staticmethod
+    def isp_loss_value(out):
+        """scalar the reference would log for an ISP iteration (host sync)"""
+        B, Tp, C = out["shape"]
+        cc, half = out["isp"]
+        n_s, n_w = B * Tp * C, B * C
+        g = {k: v.double().sum(0).cpu() for k, v in out.items() if isinstance(v, torch.Tensor)}
+        loss = g["syn"][0] / n_s + g["syn"][1] / n_w                                   # strong + weak class (syn)
+        loss += g["real"][1] / n_w + cc * (g["real"][2] / n_s + g["real"][3] / n_w)     # weak class (real) + consistency
+        loss += g["syn_fshift"][1] / n_w + g["real_fshift_weak_half"][1] / (max(half, 1) * C)  # weak freq-shift class
+        loss += g["syn_shift"][0] / n_s                                                 # strong shift class
+        loss += g["syn_fshift"][0] / n_s                                                # strong freq-shift class
+        loss += 0.5 * cc * (g["syn_shift"][2] / n_s + g["real_shift"][4] / n_s)        # consistency_loss_shift
+        fs = g["real_fshift_weak_half"][2] + (g["real_fshift_rest"][2] if half < B else 0.0)
+        loss += 0.5 * cc * (g["real_shift"][2] / n_s + fs / n_s)                         # 1/2 (strong shift + freq shift vs EMA)
+        return float(loss)
+
     @staticmethod
     def loss_value(out, consistency_cost=1.0):
         """Host-side assembly of the scalar the reference logs (syncs: call it outside the timed loop)."""

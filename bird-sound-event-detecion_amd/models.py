@@ -418,7 +418,8 @@ class Predictor(_FlatModule):
         C = self.nclass
         w, _ = self._wb()
         strong, sof, weak, den = saved
-        dx, dw_part, db_part, loss_part = ops.head_bwd(x.contiguous(), w, strong, sof, weak, den, B, T, K, C,
+        dx, dw_part, db_part, loss_part = ops.head_bwd(x.contiguous(), w, strong.contiguous(), sof.contiguous(),
+                                                       weak.contiguous(), den.contiguous(), B, T, K, C,
                                                        self.attention, **loss_kw)
         ops.reduce_partials(dw_part, B, 1, 2 * C, K, 2 * C, K, self.flat_grad, 0, K, 1)
         ops.colsum(db_part, B, 2 * C, 2 * C, self.flat_grad[2 * C * K:])

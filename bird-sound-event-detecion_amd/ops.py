@@ -32,9 +32,9 @@ class WgradDesc(ctypes.Structure):
 
 class HeadBwdDesc(ctypes.Structure):
     _fields_ = ([(n, _fp) for n in ("x", "w", "strong", "sof_raw", "weak", "den", "y_strong", "y_weak", "ema_strong",
-                                    "ema_weak", "g_strong_ext", "g_weak_ext")]
-                + [(n, ctypes.c_float) for n in ("w_strong", "w_weak", "w_cons_s", "w_cons_w", "inv_n_strong",
-                                                 "inv_n_weak")]
+                                    "ema_weak", "ema_strong2", "g_strong_ext", "g_weak_ext")]
+                + [(n, ctypes.c_float) for n in ("w_strong", "w_weak", "w_cons_s", "w_cons_w", "w_cons_s2",
+                                                 "inv_n_strong", "inv_n_weak")]
                 + [(n, _fp) for n in ("dx", "dw_part", "db_part", "loss_part")]
                 + [(n, _i) for n in ("B", "T", "K", "C", "attention")])
 
@@ -334,18 +334,22 @@ def head_fwd(x, w, b, B, T, K, C, attention):
 
 
 def head_bwd(x, w, strong, sof, weak, den, B, T, K, C, attention, y_strong=None, y_weak=None, ema_strong=None,
-             ema_weak=None, g_strong=None, g_weak=None, w_strong=1.0, w_weak=1.0, w_cons_s=0.0, w_cons_w=0.0):
+             ema_weak=None, g_strong=None, g_weak=None, w_strong=1.0, w_weak=1.0, w_cons_s=0.0, w_cons_w=0.0,
+             ema_strong2=None, w_cons_s2=0.0, n_strong=None, n_weak=None):
+    """n_strong / n_weak: element counts the 'mean' reductions divide by (default B*T*C and B*C; pass the FULL batch
+    counts when the call covers only a slice of the batch)"""
     dev = x.device
     d = HeadBwdDesc()
     dx = torch.empty((B, T, K), device=dev, dtype=torch.float32)
     dw_part = torch.empty((B, 2 * C, K), device=dev, dtype=torch.float32)
     db_part = torch.empty((B, 2 * C), device=dev, dtype=torch.float32)
-    loss_part = torch.empty((B, 4), device=dev, dtype=torch.float32)
+    loss_part = torch.empty((B, 6), device=dev, dtype=torch.float32)
     d.x = _p(x); d.w = _dp(w); d.strong = _p(strong); d.sof_raw = _p(sof); d.weak = _p(weak); d.den = _p(den)
     d.y_strong = _p(y_strong); d.y_weak = _p(y_weak); d.ema_strong = _p(ema_strong); d.ema_weak = _p(ema_weak)
-    d.g_strong_ext = _p(g_strong); d.g_weak_ext = _p(g_weak)
-    d.w_strong, d.w_weak, d.w_cons_s, d.w_cons_w = w_strong, w_weak, w_cons_s, w_cons_w
-    d.inv_n_strong, d.inv_n_weak = 1.0 / (B * T * C), 1.0 / (B * C)
+    d.g_strong_ext = _p(g_strong); d.g_weak_ext = _p(g_weak); d.ema_strong2 = _p(ema_strong2)
+    d.w_strong, d.w_weak, d.w_cons_s, d.w_cons_w, d.w_cons_s2 = w_strong, w_weak, w_cons_s, w_cons_w, w_cons_s2
+    d.inv_n_strong = 1.0 / (n_strong if n_strong else B * T * C)
+    d.inv_n_weak = 1.0 / (n_weak if n_weak else B * C)
     d.dx = _p(dx); d.dw_part = _p(dw_part); d.db_part = _p(db_part); d.loss_part = _p(loss_part)
     d.B, d.T, d.K, d.C, d.attention = B, T, K, C, 1 if attention else 0
     L.call("bsed_head_bwd", ctypes.byref(d), L.stream())
@@ -362,6 +366,14 @@ def sgd_step(p, g, buf, lr, momentum, weight_decay, first_step, nesterov=True, g
     L.call("bsed_sgd_step", L.ptr(p), L.ptr(g), L.ptr(buf), ctypes.c_long(p.numel()), ctypes.c_float(lr),
            ctypes.c_float(momentum), ctypes.c_float(weight_decay), _i(1 if first_step else 0),
            _i(1 if nesterov else 0), ctypes.c_float(grad_scale), L.stream())
+
+
+def roll(x, B, H, W, sh=None, sw=None):
+    """per-sample torch.roll of a contiguous (B,H,W[,..]) tensor viewed as (B,H,W); sh/sw: int32 device tensors (B)"""
+    out = torch.empty_like(x)
+    L.call("bsed_roll", L.ptr(x), L.ptr(out), _i(B), _i(H), _i(W), L.ptr(sh, torch.int32), L.ptr(sw, torch.int32),
+           L.stream())
+    return out
 
 
 def axpy(y, x, a=1.0):

@@ -245,14 +245,15 @@ typedef struct BsedHeadBwdDesc {
   const float* y_weak;       /* (B,C)   or NULL: BCE(weak, y)   * w_weak */
   const float* ema_strong;   /* (B,T,C) or NULL: MSE(strong, ema) * w_cons_s */
   const float* ema_weak;     /* (B,C)   or NULL: MSE(weak, ema)   * w_cons_w */
+  const float* ema_strong2;  /* (B,T,C) or NULL: second MSE target on strong * w_cons_s2 (ISP shift consistency) */
   const float* g_strong_ext; /* (B,T,C) or NULL: upstream dL/dstrong (autograd drop-in path) */
   const float* g_weak_ext;   /* (B,C)   or NULL */
-  float w_strong, w_weak, w_cons_s, w_cons_w;
+  float w_strong, w_weak, w_cons_s, w_cons_w, w_cons_s2;
   float inv_n_strong, inv_n_weak; /* 1/(B*T*C), 1/(B*C): reduction='mean' */
   float* dx;                 /* (B,T,K) */
   float* dw_part;            /* (B,2C,K) per-clip partials for bsed_reduce_partials */
   float* db_part;            /* (B,2C) */
-  float* loss_part;          /* (B,4): plain sums of BCE_strong, BCE_weak, SE_strong, SE_weak */
+  float* loss_part;          /* (B,6): plain sums of BCE_strong, BCE_weak, SE_strong, SE_weak, SE_strong2, 0 */
   int B, T, K, C, attention;
 } BsedHeadBwdDesc;
 
@@ -271,6 +272,9 @@ int bsed_sgd_step(float* p, const float* g, float* buf, long n, float lr, float 
 int bsed_ema_update(float* ema, const float* p, long n, float alpha, void* stream);
 int bsed_ema_update_i64(long long* ema, const long long* p, int n, float alpha, void* stream);
 int bsed_scale(float* x, long n, float s, void* stream);
+/* per-sample circular shift (torch.roll) of a (B,H,W) tensor: out[b][h][w] = in[b][(h-sh[b]) mod H][(w-sw[b]) mod W];
+ * sh / sw are DEVICE int32 arrays (B) or NULL.  Reference src/main_baseline.py:229-277,374-401 (ISP views). */
+int bsed_roll(const float* in, float* out, int B, int H, int W, const int* sh, const int* sw, void* stream);
 /* y += a * x  (sums the class-loss and domain-loss gradients at the encoder output) */
 int bsed_axpy(float* y, const float* x, long n, float a, void* stream);
 

@@ -264,3 +264,51 @@ def train_losses(crnn, pred, x_syn, y_syn, x_real=None, y_weak_real=None, ema=No
             loss = loss + consistency_cost * mse(weak_r, weak_e) + consistency_cost * mse(strong_r, strong_e)
     out["loss"] = loss
     return loss, out
+
+
+def _roll_each(x, shifts, dim):
+    """per-sample torch.roll, as the reference's python loops do (src/main_baseline.py:234-246, 375-388)"""
+    return torch.stack([torch.roll(x[k], int(shifts[k]), dims=dim) for k in range(x.shape[0])], 0)
+
+
+def train_losses_isp(crnn, pred, ema, x_syn, y_syn, x_real, y_weak_real, x_real_ema, shift_frames, shift_bins,
+                     consistency_cost=1.0, pooling_time_ratio=4):
+    """Loss of one ``train_mt`` iteration with ``-mt -ISP`` (src/main_baseline.py:229-277, 337-420, 431-529)."""
+    bce, mse = nn.BCELoss(), nn.MSELoss()
+    cc = consistency_cost
+    weak_index = y_weak_real.shape[0] // 2
+    # inputs are (B,1,T,F): sample k is (1,T,F) -> time is dim 1, frequency dim 2
+    x_real_sh, x_real_fs = _roll_each(x_real, shift_frames, 1), _roll_each(x_real, shift_bins, 2)
+    x_ema_sh, x_ema_fs = _roll_each(x_real_ema, shift_frames, 1), _roll_each(x_real_ema, shift_bins, 2)
+    x_syn_sh, x_syn_fs = _roll_each(x_syn, shift_frames, 1), _roll_each(x_syn, shift_bins, 2)
+    pool_shift = [int(s / pooling_time_ratio) for s in shift_frames]
+
+    enc_s, _ = crnn(x_syn); strong_s, weak_s = pred(enc_s)
+    enc_r, _ = crnn(x_real); strong_r, weak_r = pred(enc_r)
+    with torch.no_grad():
+        se, we = ema[1](ema[0](x_real_ema)[0])
+        se_sh, _ = ema[1](ema[0](x_ema_sh)[0])
+        se_fs, _ = ema[1](ema[0](x_ema_fs)[0])
+    strong_r_roll = _roll_each(strong_r, pool_shift, 0).detach()
+    strong_s_roll = _roll_each(strong_s, pool_shift, 0).detach()
+    y_syn_roll = _roll_each(y_syn, pool_shift, 0)
+    strong_r_sh, weak_r_sh = pred(crnn(x_real_sh)[0])
+    strong_r_fs, weak_r_fs = pred(crnn(x_real_fs)[0])
+    strong_s_sh, weak_s_sh = pred(crnn(x_syn_sh)[0])
+    strong_s_fs, weak_s_fs = pred(crnn(x_syn_fs)[0])
+
+    y_weak_syn = y_syn.max(-2)[0]
+    weak_class = bce(weak_s, y_weak_syn) + bce(weak_r, y_weak_real)
+    weak_fs_class = bce(weak_s_fs, y_weak_syn) + bce(weak_r_fs[:weak_index], y_weak_real[:weak_index])
+    strong_class = bce(strong_s, y_syn)
+    strong_sh_class = bce(strong_s_sh, y_syn_roll)
+    strong_fs_class = bce(strong_s_fs, y_syn)
+    cons_strong = cc * mse(strong_r, se)
+    cons_weak = cc * mse(weak_r, we)
+    cons_strong_sh = cc * mse(strong_r_sh, se_sh)
+    cons_strong_fs = cc * mse(strong_r_fs, se_fs)
+    loss = strong_class + weak_class + (cons_weak + cons_strong)
+    cons_shift = cc / 2 * (mse(strong_s_sh, strong_s_roll) + mse(strong_r_sh, strong_r_roll))
+    loss = loss + (weak_fs_class + strong_sh_class + strong_fs_class + cons_shift)
+    loss = loss + 1 / 2 * (cons_strong_sh + cons_strong_fs)
+    return loss

@@ -318,3 +318,37 @@ def test_fused_glu_backward_matches_unfused_chain():
         grads.append(crnn.flat_grad.clone())
     err = float((grads[0] - grads[1]).norm() / grads[1].norm())
     assert err < 2e-5, err
+
+
+def test_isp_shift_consistency_step_matches_oracle():
+    """-mt -ISP iteration (time / frequency rolled views, 6 student + 3 teacher forwards): loss and gradients"""
+    from bsed_amd.engine import FlatSGD, SEDTrainer
+    seed, B, T = 41, 4, 128
+    rng = np.random.default_rng(seed)
+    xs = seeded.db_like_input(seed + 1, B, T); xr = seeded.db_like_input(seed + 2, B, T)
+    xe = xr + rng.normal(0, 1.0, xr.shape).astype(np.float32)
+    y = seeded.strong_targets(seed + 3, B, T // 4)
+    yw = (rng.random((B, 20)) < 0.2).astype(np.float32)
+    shift_frames, shift_bins = [-8, 12, 0, 40], [3, -2, 0, -4]
+    ocrnn, opred = _oracle(0.0, seed)
+    oema_c, oema_p = _oracle(0.0, seed + 5)
+    for m in (ocrnn, opred, oema_c, oema_p):
+        m.train()
+    tt = torch.from_numpy
+    loss_ref = co.train_losses_isp(ocrnn, opred, (oema_c, oema_p), tt(xs), tt(y), tt(xr), tt(yw), tt(xe),
+                                   shift_frames, shift_bins, consistency_cost=0.6)
+    loss_ref.backward()
+
+    ocrnn2, _ = _oracle(0.0, seed)
+    oema_c2, _ = _oracle(0.0, seed + 5)
+    crnn, pred = _mine(0.0, ocrnn2, opred)
+    ema_c, ema_p = _mine(0.0, oema_c2, oema_p)
+    tr = SEDTrainer(crnn, pred, ema_c, ema_p, optimizer=FlatSGD([crnn, pred], lr=0.0, momentum=0.0, weight_decay=0.0))
+    out = tr.train_step_isp(tt(xs).cuda(), tt(y).cuda(), tt(xr).cuda(), tt(yw).cuda(), tt(xe).cuda(), shift_frames,
+                            shift_bins, consistency_cost=0.6)
+    loss = SEDTrainer.isp_loss_value(out)
+    assert abs(loss - float(loss_ref)) < 3e-5 * abs(loss), (loss, float(loss_ref))
+    bad = _grad_check(pred, {k: p.grad for k, p in opred.named_parameters()}, tol=3e-4)
+    assert not bad, bad
+    bad = _grad_check(crnn, {k: p.grad for k, p in ocrnn.named_parameters()}, tol=3e-4)
+    assert not bad, bad
