@@ -226,6 +226,42 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_kernel(
   }
 }
 
+// Event post-processing of get_predictions (reference src/evaluation_measures.py:188-205): binarise at `threshold`, then
+// scipy.ndimage.median_filter(size=(win,1)) along time with scipy's conventions -- window [t - win/2, t - win/2 + win),
+// 'reflect' boundary (d c b a | a b c d | d c b a), rank win/2 of the sorted window, i.e. for 0/1 data the output is 1
+// iff the window holds at least win - win/2 ones.
+__global__ void binarize_median_kernel(const float* __restrict__ strong, float* __restrict__ out, int B, int T, int C,
+                                       float threshold, int win) {
+  const long total = (long)B * T * C;
+  const int need = win - win / 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const int t = (int)(r % T);
+    const long b = r / T;
+    int ones = 0;
+    for (int k = 0; k < win; ++k) {
+      int tt = t - win / 2 + k;
+      // reflect (edge sample repeated): -1 -> 0, -2 -> 1, T -> T-1, T+1 -> T-2; period 2T
+      tt %= 2 * T;
+      if (tt < 0) tt += 2 * T;
+      if (tt >= T) tt = 2 * T - 1 - tt;
+      ones += strong[(b * T + tt) * C + c] > threshold ? 1 : 0;
+    }
+    out[i] = ones >= need ? 1.f : 0.f;
+  }
+}
+
+extern "C" int bsed_binarize_median(const float* strong, float* out, int B, int T, int C, float threshold, int win,
+                                    void* stream) {
+  BSED_CHECK_ARG(strong && out && strong != out && B > 0 && T > 0 && C > 0 && win >= 1, "bsed_binarize_median: bad argument");
+  const long total = (long)B * T * C;
+  hipLaunchKernelGGL(binarize_median_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256),
+                     0, (hipStream_t)stream, strong, out, B, T, C, threshold, win);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
 extern "C" int bsed_head_fwd(const float* x, const float* w, const float* b, float* strong, float* sof_raw,
                              float* weak, float* den, int B, int T, int K, int C, int attention, void* stream) {
   BSED_CHECK_ARG(x && w && b && strong && sof_raw && weak && den, "bsed_head_fwd: null tensor");

@@ -221,6 +221,29 @@ __global__ void mel_noise_kernel(const float* __restrict__ x, const float* __res
   if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(clip_max + b), __float_as_int(vmax));
 }
 
+// per-clip max and per-(clip, band) sum over time of x^2 for features that arrive as LINEAR mel (.npy files of the
+// reference) instead of waveforms: one workgroup per clip, thread = band
+__global__ __launch_bounds__(256) void mel_stats_kernel(const float* __restrict__ x, float* __restrict__ clip_max,
+                                                        float* __restrict__ bin_sumsq, int T, int n_mels) {
+  __shared__ float red[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float mx = 0.f, sq = 0.f;
+  if (tid < n_mels)
+    for (int t = 0; t < T; ++t) {
+      const float v = x[((size_t)b * T + t) * n_mels + tid];
+      mx = fmaxf(mx, v);
+      sq = fmaf(v, v, sq);
+    }
+  if (tid < n_mels) bin_sumsq[(size_t)b * n_mels + tid] = sq;
+  red[tid] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+    __syncthreads();
+  }
+  if (tid == 0) clip_max[b] = red[0];
+}
+
 // dB + top_db clamp + pad/trunc of the time axis (pad value 0 dB, Transforms.py:89-109)
 __global__ void mel_db_kernel(const float* __restrict__ x, const float* __restrict__ clip_max,
                               float* __restrict__ out, int T, int T_out, int n_mels, float top_db) {
@@ -319,6 +342,14 @@ extern "C" int bsed_mel_linear(const void* plan, const float* wav, int B, int n_
   hipLaunchKernelGGL(stft_mel_kernel, grid, dim3(MEL_THREADS), smem, s, wav, n_samples, p->cfg.hop, T,
                      p->cfg.n_mels, p->d_window, p->d_w1024, p->d_w2048, p->d_mel_start, p->d_mel_count,
                      p->d_mel_off, p->d_mel_w, mel_lin, clip_max, bin_sumsq, span_len);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_mel_stats(const float* mel_lin, int B, int T, int n_mels, float* clip_max, float* bin_sumsq,
+                              void* stream) {
+  BSED_CHECK_ARG(mel_lin && clip_max && bin_sumsq && B > 0 && T > 0 && n_mels > 0 && n_mels <= 256, "bsed_mel_stats: bad argument");
+  hipLaunchKernelGGL(mel_stats_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mel_lin, clip_max, bin_sumsq, T, n_mels);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }

@@ -25,6 +25,19 @@ def post_process(pred_strong, decoder, threshold=0.5, median_window=1, pooling_t
             for lab, on, off in decoder(binar)]
 
 
+def binarize_median_gpu(pred_strong, threshold=0.5, median_window=1):
+    """(B,T',C) GPU probabilities -> (B,T',C) 0/1 mask: threshold + scipy-compatible median filter, one HIP kernel
+    for the whole batch instead of a per-clip scipy call"""
+    import ctypes
+    from . import _lib as L
+    x = pred_strong.contiguous()
+    B, T, C = x.shape
+    out = torch.empty_like(x)
+    L.call("bsed_binarize_median", L.ptr(x), L.ptr(out), L.c_int(B), L.c_int(T), L.c_int(C), ctypes.c_float(threshold),
+           L.c_int(median_window), L.stream())
+    return out
+
+
 def get_predictions(model, dataloader, decoder, pooling_time_ratio=1, thresholds=(0.5,), median_window=1,
                     save_predictions=None, del_model=False, learned_post=False, predictor=None, fpn=False,
                     saved_feature_dir=None, sr=32000, hop_size=255, max_len_seconds=10.0):
@@ -48,12 +61,14 @@ def get_predictions(model, dataloader, decoder, pooling_time_ratio=1, thresholds
             pred_strong, _ = predictor(encoded_x, inference=fpn)
         if saved_feature_dir is not None:
             np.save(os.path.join(saved_feature_dir, f"{i}"), feature_out.cpu().numpy())
-        pred_strong = pred_strong.cpu().numpy()
-        for j, ps in enumerate(pred_strong):
-            for t in thresholds:
-                for lab, on, off in post_process(ps, decoder, t, median_window, pooling_time_ratio, sr, hop_size,
-                                                 max_len_seconds):
-                    rows[t].append({"event_label": lab, "onset": on, "offset": off, "filename": names[j]})
+        scale = pooling_time_ratio / (sr / hop_size)
+        for t in thresholds:
+            # threshold + median filter for the whole batch on the GPU; only the 0/1 masks travel to the host
+            masks = binarize_median_gpu(pred_strong, t, median_window).cpu().numpy()
+            for j, m in enumerate(masks):
+                for lab, on, off in decoder(m):
+                    rows[t].append({"event_label": lab, "onset": float(np.clip(on * scale, 0, max_len_seconds)),
+                                    "offset": float(np.clip(off * scale, 0, max_len_seconds)), "filename": names[j]})
     model.train(was_training[0]); predictor.train(was_training[1])
     dfs = [pd.DataFrame(rows[t], columns=["event_label", "onset", "offset", "filename"]) for t in thresholds]
     if save_predictions is not None:

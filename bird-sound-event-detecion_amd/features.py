@@ -64,6 +64,15 @@ class MelFrontEnd:
                L.ptr(sumsq), L.stream())
         return mel, cmax, sumsq
 
+    def stats(self, mel_lin):
+        """(clip_max (B,), bin_sumsq (B,n_mels)) of a linear-mel batch (for features loaded from .npy files)"""
+        B, T, M = mel_lin.shape
+        cmax = torch.empty((B,), device=mel_lin.device, dtype=torch.float32)
+        sumsq = torch.empty((B, M), device=mel_lin.device, dtype=torch.float32)
+        L.call("bsed_mel_stats", L.ptr(mel_lin), L.c_int(B), L.c_int(T), L.c_int(M), L.ptr(cmax), L.ptr(sumsq),
+               L.stream())
+        return cmax, sumsq
+
     def to_db(self, mel_lin, clip_max, max_frames=None):
         B, T, M = mel_lin.shape
         T_out = T if max_frames is None else max_frames

@@ -51,6 +51,8 @@ int bsed_mel_num_frames(const void* plan, int n_samples);   /* 1 + n_samples / h
  * the SNR noise need, so neither costs another pass over HBM. */
 int bsed_mel_linear(const void* plan, const float* wav, int B, int n_samples, float* mel_lin,
                     float* clip_max, float* bin_sumsq, void* stream);
+/* the same two statistics for features that arrive as linear mel (the reference's wav/<name>.npy files) */
+int bsed_mel_stats(const float* mel_lin, int B, int T, int n_mels, float* clip_max, float* bin_sumsq, void* stream);
 /* noisy = mel + N(0,1) * sqrt(mean_t(mel^2) * 10^(-snr/10))  (AugmentGaussianNoise.gaussian_noise).
  * unit_noise (B,T,n_mels) may inject the N(0,1) draws (parity tests); NULL = Philox(seed). */
 int bsed_mel_noise(const float* mel_lin, const float* bin_sumsq, const float* unit_noise, int B, int T,
@@ -233,6 +235,11 @@ int bsed_gru_bwd(const float* dout, const float* out, const float* gates, const 
  * ---------------------------------------------------------------------------------------------- */
 int bsed_head_fwd(const float* x, const float* w, const float* b, float* strong, float* sof_raw, float* weak,
                   float* den, int B, int T, int K, int C, int attention, void* stream);
+
+/* get_predictions post-processing (src/evaluation_measures.py:188-205): out = median_filter(strong > threshold,
+ * size=(win,1)) with scipy.ndimage's window origin and 'reflect' boundary; (B,T,C) float 0/1 mask */
+int bsed_binarize_median(const float* strong, float* out, int B, int T, int C, float threshold, int win,
+                         void* stream);
 
 typedef struct BsedHeadBwdDesc {
   const float* x;            /* (B,T,K) encoder output */
