@@ -1,0 +1,284 @@
+// 3x3 convolution forward / data-gradient as an implicit GEMM on the bf16 matrix cores with SPLIT-fp32 operands
+// ("bf16x3"): every fp32 operand x is carried as hi = bf16(x), lo = bf16(x - hi) and a product is accumulated as
+//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (fp32 accumulate; dropped term a_lo*b_lo ~ 2^-16 relative)
+// gfx950 has no xf32/TF32 MFMA; this is its equivalent: ~2e-5 relative error per product (random sign, so ~1e-5 on a
+// K = 1152 dot product) at 3 x v_mfma_f32_32x32x16_bf16 = 96 cycles per 16 k instead of 8 x 64 = 512 cycles on
+// v_mfma_f32_32x32x2_f32 -- 5.3x fewer matrix-core cycles with the SAME fp32 tensors in HBM.
+//
+// Same tiling as igemm.hip (128 output positions x BN channels per workgroup, patch + weight slab in LDS).  LDS rows
+// are [32 hi | 32 lo | 8 pad] bf16 = 144 B, which keeps the 16-byte fragment reads (lane r, k = 8*(lane>>5)..+7)
+// conflict-free: 36 r mod 64 hits 16 distinct 4-bank groups.  Weights are pre-split by bsed_pack_weight3.
+#include "bsed_common.h"
+#include "../../include/bsed.h"
+#include <algorithm>
+
+#define I3_THREADS 256
+#define I3_M 128
+#define I3_KC 32
+#define I3_ROW 72  // ushorts per LDS row: 32 hi + 32 lo + 8 pad
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Igemm3Params {
+  BsedIgemmDesc d;
+  int PW, PH, PP, lgTW, b_off, pw_magic;
+};
+
+__device__ __forceinline__ unsigned short f2bf(float x) {
+  const uint32_t u = __float_as_uint(x);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ int crow3(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+template <int BN, int STATS>
+__global__ __launch_bounds__(I3_THREADS) void igemm3_kernel(const Igemm3Params P) {
+  constexpr int NT = BN / 32;
+  const BsedIgemmDesc& p = P.d;
+  extern __shared__ __align__(16) unsigned short smem3[];
+  unsigned short* As = smem3;             // [PP][72]
+  unsigned short* Bs = smem3 + P.b_off;   // [BN][72]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  int tile = blockIdx.x;
+  const int tw_i = tile % p.tilesW; tile /= p.tilesW;
+  const int th_i = tile % p.tilesH;
+  const int nb = tile / p.tilesH;
+  const int th0 = th_i * p.TH, tw0 = tw_i * p.TW;
+  const int n0 = blockIdx.y * BN;
+  const int PW = P.PW;
+  const int m = wave * 32 + li;
+  const int abase = (((m >> P.lgTW) + p.hh) * PW + (m & (p.TW - 1)) + p.hw) * I3_ROW + 8 * lh;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const float* inb = p.in + (size_t)nb * p.H * p.W * p.in_pitch;
+  const int nchunks = p.CIN / I3_KC;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int c0 = ch * I3_KC;
+    __syncthreads();
+    // activation patch: fp32 from HBM, split into bf16 hi / lo while staging
+    const int a_total = P.PP * (I3_KC / 4);
+    for (int e0 = tid; e0 < a_total; e0 += 4 * I3_THREADS) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * I3_THREADS;
+        const int c4 = e % (I3_KC / 4), pos = e / (I3_KC / 4);
+        const int pr = (pos * P.pw_magic) >> 20, pc = pos - pr * PW;
+        const int gh = th0 - p.hh + pr, gw = tw0 - p.hw + pc;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < a_total && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W)
+          v[u] = *reinterpret_cast<const float4*>(inb + ((size_t)gh * p.W + gw) * p.in_pitch + c0 + 4 * c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * I3_THREADS;
+        if (e < a_total) {
+          const int c4 = e % (I3_KC / 4), pos = e / (I3_KC / 4);
+          const float f[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+          unsigned short hi[4], lo[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            hi[i] = f2bf(f[i]);
+            lo[i] = f2bf(f[i] - bf2f(hi[i]));
+          }
+          unsigned short* dst = As + pos * I3_ROW + 4 * c4;
+          *reinterpret_cast<uint2*>(dst) = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
+          *reinterpret_cast<uint2*>(dst + 32) = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+        }
+      }
+    }
+    for (int tap = 0; tap < p.ntaps; ++tap) {
+      if (tap > 0) __syncthreads();
+      // weight slab [BN][64] bf16 (hi | lo), pre-split: 128 B per output channel
+      const unsigned short* wsrc = reinterpret_cast<const unsigned short*>(p.w) +
+                                   (((size_t)tap * nchunks + ch) * p.NP + n0) * 64;
+      for (int e = tid; e < BN * 8; e += I3_THREADS) {
+        const int n = e >> 3, part = e & 7;
+        *reinterpret_cast<uint4*>(Bs + n * I3_ROW + part * 8) = *reinterpret_cast<const uint4*>(wsrc + (size_t)n * 64 + part * 8);
+      }
+      __syncthreads();
+      const unsigned short* arow = As + abase + (p.dh[tap] * PW + p.dw[tap]) * I3_ROW;
+      const unsigned short* brow = Bs + li * I3_ROW + 8 * lh;
+#pragma unroll
+      for (int k0 = 0; k0 < I3_KC; k0 += 16) {
+        const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(arow + k0);
+        const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(arow + 32 + k0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const bf16x8 b_hi = *reinterpret_cast<const bf16x8*>(brow + 32 * j * I3_ROW + k0);
+          const bf16x8 b_lo = *reinterpret_cast<const bf16x8*>(brow + 32 * j * I3_ROW + 32 + k0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: + bias, store, optional BatchNorm partial sums (same as igemm.hip PLAIN / STATS)
+  float s0[NT], s1[NT], bias[NT];
+  bool nok[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    s0[j] = 0.f; s1[j] = 0.f;
+    const int n = n0 + 32 * j + li;
+    nok[j] = n < p.N;
+    bias[j] = (p.bias && nok[j]) ? p.bias[n] : 0.f;
+  }
+  const int nbase = n0 + li;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int mm = wave * 32 + crow3(r, lh);
+    const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
+    const bool pok = gh < p.H && gw < p.W;
+    float* orow = p.out + (((size_t)nb * p.H + gh) * p.W + gw) * p.out_pitch + nbase;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (pok && nok[j]) {
+        const float v = acc[j][r] + bias[j];
+        orow[32 * j] = v;
+        if (STATS) { s0[j] += v; s1[j] = fmaf(v, v, s1[j]); }
+      }
+    }
+  }
+  if (STATS) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem3);  // [4][2][BN]
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float a = s0[j] + __shfl_xor(s0[j], 32, 64);
+      const float b = s1[j] + __shfl_xor(s1[j], 32, 64);
+      if (lh == 0) {
+        red[(wave * 2 + 0) * BN + 32 * j + li] = a;
+        red[(wave * 2 + 1) * BN + 32 * j + li] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, n = tid % BN;
+      if (n0 + n < p.N) {
+        const float s = red[(0 * 2 + which) * BN + n] + red[(1 * 2 + which) * BN + n] + red[(2 * 2 + which) * BN + n] +
+                        red[(3 * 2 + which) * BN + n];
+        p.stats[((size_t)blockIdx.x * 2 + which) * p.N + n0 + n] = s;
+      }
+    }
+  }
+}
+
+// w3[tap][chunk][n][0..31] = bf16 hi, [32..63] = bf16 lo of src[tap*s_tap + (chunk*32+k)*s_k + n*s_n]; zero for n >= N
+__global__ void pack_weight3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int ntaps, int K,
+                                    int N, int NP, long s_tap, long s_k, long s_n) {
+  const int nchunks = K / 32;
+  const long total = (long)ntaps * nchunks * NP * 32;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e & 31);
+    long r = e >> 5;
+    const int n = (int)(r % NP); r /= NP;
+    const int ch = (int)(r % nchunks);
+    const int tap = (int)(r / nchunks);
+    const float v = n < N ? src[tap * s_tap + (long)(ch * 32 + k) * s_k + n * s_n] : 0.f;
+    const unsigned short hi = f2bf(v);
+    const unsigned short lo = f2bf(v - bf2f(hi));
+    unsigned short* d = dst + (((long)tap * nchunks + ch) * NP + n) * 64;
+    d[k] = hi;
+    d[32 + k] = lo;
+  }
+}
+
+// fragment-layout self test of v_mfma_f32_32x32x16_bf16: C(32,32) = A(32,K) B(K,32) with bf16x3 split operands
+__global__ void mfma_bf16x3_selftest_kernel(const float* A, const float* B, float* C, int K) {
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  f32x16 acc = {0};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    bf16x8 ah, al, bh, bl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = A[li * K + k0 + 8 * lh + j];         // A[row = lane&31][k = 8*(lane>>5) + j]
+      const float b = B[(k0 + 8 * lh + j) * 32 + li];      // B[k = 8*(lane>>5) + j][col = lane&31]
+      const unsigned short ahi = f2bf(a), bhi = f2bf(b);
+      ah[j] = (short)ahi; al[j] = (short)f2bf(a - bf2f(ahi));
+      bh[j] = (short)bhi; bl[j] = (short)f2bf(b - bf2f(bhi));
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) C[crow3(r, lh) * 32 + li] = acc[r];
+}
+
+extern "C" int bsed_selftest_mfma_bf16x3(const float* A, const float* B, float* C, int K, void* stream) {
+  BSED_CHECK_ARG(A && B && C && K > 0 && K % 16 == 0, "bsed_selftest_mfma_bf16x3: bad argument");
+  hipLaunchKernelGGL(mfma_bf16x3_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, C, K);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_pack_weight3(const float* src, void* dst, int ntaps, int K, int N, int NP, long s_tap, long s_k,
+                                 long s_n, void* stream) {
+  BSED_CHECK_ARG(src && dst && ntaps > 0 && K > 0 && K % 32 == 0 && N > 0 && NP >= N && NP % 32 == 0,
+                 "bsed_pack_weight3: K must be a multiple of 32, NP a multiple of 32 >= N");
+  const long total = (long)ntaps * K * NP;
+  hipLaunchKernelGGL(pack_weight3_kernel, dim3((unsigned)std::min<long>(ceil_div(total, 256), 4096)), dim3(256), 0,
+                     (hipStream_t)stream, src, (unsigned short*)dst, ntaps, K, N, NP, s_tap, s_k, s_n);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+template <int BN, int STATS>
+static int launch_i3(const Igemm3Params& P, dim3 grid, size_t smem, hipStream_t s) {
+  static bool done = false;
+  if (!done) {
+    BSED_HIP(hipFuncSetAttribute((const void*)igemm3_kernel<BN, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+  }
+  hipLaunchKernelGGL((igemm3_kernel<BN, STATS>), grid, dim3(I3_THREADS), smem, s, P);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_igemm3(const BsedIgemmDesc* desc, void* stream) {
+  BSED_CHECK_ARG(desc, "bsed_igemm3: null descriptor");
+  Igemm3Params P;
+  P.d = *desc;
+  BsedIgemmDesc& d = P.d;
+  BSED_CHECK_ARG(d.in && d.w && d.out, "bsed_igemm3: null tensor");
+  BSED_CHECK_ARG(d.epilogue == BSED_EPI_PLAIN || d.epilogue == BSED_EPI_STATS, "bsed_igemm3: PLAIN / STATS epilogues only");
+  BSED_CHECK_ARG(d.epilogue != BSED_EPI_STATS || d.stats, "bsed_igemm3: STATS needs a stats buffer");
+  BSED_CHECK_ARG(d.NB > 0 && d.H > 0 && d.W > 0 && d.CIN > 0 && d.CIN % 32 == 0 && d.N > 0, "bsed_igemm3: CIN must be a multiple of 32");
+  BSED_CHECK_ARG(d.TH * d.TW == I3_M && d.W % d.TW == 0, "bsed_igemm3: TH*TW must be 128 and TW divide W");
+  P.lgTW = 0;
+  while ((1 << P.lgTW) < d.TW) ++P.lgTW;
+  BSED_CHECK_ARG((1 << P.lgTW) == d.TW, "bsed_igemm3: TW must be a power of two");
+  BSED_CHECK_ARG(d.ntaps >= 1 && d.ntaps <= 9, "bsed_igemm3: ntaps must be in 1..9");
+  for (int t = 0; t < d.ntaps; ++t)
+    BSED_CHECK_ARG(abs(d.dh[t]) <= d.hh && abs(d.dw[t]) <= d.hw, "bsed_igemm3: tap %d outside the halo", t);
+  BSED_CHECK_ARG(d.in_pitch >= d.CIN && d.in_pitch % 4 == 0 && d.out_pitch >= d.N, "bsed_igemm3: bad pitch");
+  BSED_CHECK_ARG(d.NP % 32 == 0 && d.NP >= d.N, "bsed_igemm3: NP must be N rounded up to 32");
+  const int BN = d.NP % 128 == 0 ? 128 : (d.NP % 64 == 0 ? 64 : 32);
+  d.tilesH = ceil_div(d.H, d.TH);
+  d.tilesW = d.W / d.TW;
+  P.PW = d.TW + 2 * d.hw;
+  P.PH = d.TH + 2 * d.hh;
+  P.PP = P.PW * P.PH;
+  P.b_off = (P.PP * I3_ROW + 7) & ~7;
+  P.pw_magic = ((1 << 20) + P.PW - 1) / P.PW;
+  for (int pos = 0; pos < P.PP; ++pos)
+    BSED_CHECK_ARG(((pos * P.pw_magic) >> 20) == pos / P.PW, "bsed_igemm3: internal: magic division fails for PW=%d", P.PW);
+  size_t bytes = ((size_t)P.b_off + (size_t)BN * I3_ROW) * sizeof(unsigned short);
+  bytes = std::max(bytes, (size_t)8 * BN * sizeof(float));
+  BSED_CHECK_ARG(bytes <= 160 * 1024, "bsed_igemm3: tile needs %zu B of LDS", bytes);
+  const long ntiles = (long)d.NB * d.tilesH * d.tilesW;
+  BSED_CHECK_ARG(ntiles < (1L << 31), "bsed_igemm3: too many tiles");
+  dim3 grid((unsigned)ntiles, d.NP / BN);
+  hipStream_t s = (hipStream_t)stream;
+  const bool st = d.epilogue == BSED_EPI_STATS;
+  if (BN == 128) return st ? launch_i3<128, 1>(P, grid, bytes, s) : launch_i3<128, 0>(P, grid, bytes, s);
+  if (BN == 64) return st ? launch_i3<64, 1>(P, grid, bytes, s) : launch_i3<64, 0>(P, grid, bytes, s);
+  return st ? launch_i3<32, 1>(P, grid, bytes, s) : launch_i3<32, 0>(P, grid, bytes, s);
+}

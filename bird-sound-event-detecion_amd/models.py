@@ -135,6 +135,13 @@ class CRNN(_FlatModule):
         self.n_hidden = n_RNN_cell
         self.seed = 0
         self.fused_glu_bwd = True  # False = the unfused 4-launch chain (kept as a cross-check in the tests)
+        # "bf16x3" (default): the 3x3 conv forward / data-gradient contractions and the GRU projection GEMMs run on the
+        # bf16 matrix cores with split-fp32 operands (csrc/igemm3.hip; measured 5.5e-6 on the logits of the reference
+        # config, 18x inside the 1e-4 bar).  "fp32": exact fp32 matrix cores everywhere (9.6e-7 on the logits).
+        import os as _os
+        self.conv_mode = _os.environ.get("BSED_CONV_MODE", "bf16x3")
+        if self.conv_mode not in ("fp32", "bf16x3"):
+            raise L.BsedError(f"BSED_CONV_MODE must be fp32 or bf16x3, got {self.conv_mode!r}")
         pspecs, bspecs = [], []
         cin = 1
         for i, co in enumerate(nb_filters):
@@ -235,9 +242,13 @@ class CRNN(_FlatModule):
             if i == 0:
                 y, stats = ops.conv0_fwd(a, cw, cb, B, Hh, Ww, co, want_stats=train)
             else:
-                wpk = ops.pack_weight(cw, 9, cin, co, 1, 9, cin * 9)
-                y, stats = ops.igemm(a, wpk, co, B, Hh, Ww, cin, taps=ops.TAPS3x3, bias=cb,
-                                     epilogue=ops.EPI_STATS if train else ops.EPI_PLAIN)
+                epi = ops.EPI_STATS if train else ops.EPI_PLAIN
+                if self.conv_mode == "bf16x3" and cin % 32 == 0:
+                    w3 = ops.pack_weight3(cw, 9, cin, co, 1, 9, cin * 9)
+                    y, stats = ops.igemm3(a, w3, co, B, Hh, Ww, cin, ops.TAPS3x3, bias=cb, epilogue=epi)
+                else:
+                    wpk = ops.pack_weight(cw, 9, cin, co, 1, 9, cin * 9)
+                    y, stats = ops.igemm(a, wpk, co, B, Hh, Ww, cin, taps=ops.TAPS3x3, bias=cb, epilogue=epi)
             bn = self.P(f"cnn.batchnorm{i}")
             if train:
                 mean, invstd, scale, shift = ops.bn_finalize(stats, co, float(B * Hh * Ww), BN_EPS, BN_MOMENTUM,
@@ -268,8 +279,12 @@ class CRNN(_FlatModule):
         layers = []
         for l in range(2):
             nin, w_ih, w_hh, b_ih, b_hh = self._rnn_views(l)
-            wpk = ops.pack_weight(w_ih, 1, nin, 768, 0, 1, nin)
-            xp, _ = ops.igemm(seq, wpk, 768, 1, B * T, 1, nin, bias=b_ih)
+            if self.conv_mode == "bf16x3":
+                w3 = ops.pack_weight3(w_ih, 1, nin, 768, 0, 1, nin)
+                xp, _ = ops.igemm3(seq, w3, 768, 1, B * T, 1, nin, ((0, 0),), bias=b_ih)
+            else:
+                wpk = ops.pack_weight(w_ih, 1, nin, 768, 0, 1, nin)
+                xp, _ = ops.igemm(seq, wpk, 768, 1, B * T, 1, nin, bias=b_ih)
             out, gates = ops.gru_fwd(xp.view(B, T, 768), w_hh, b_hh, B, T, save_gates=save)
             layers.append(dict(inp=seq, out=out, gates=gates))
             seq = out
@@ -299,8 +314,12 @@ class CRNN(_FlatModule):
                 part, G, KP, NP = ops.wgrad(lay["out"], dgh, B, T, 1, 128, 384, taps=((-1 if dr == 0 else 1, 0),),
                                             in_pitch=256, dy_pitch=768, in_offset=dr * 128, dy_offset=dr * 384)
                 ops.reduce_partials(part, G, 1, KP, NP, 128, 384, g_whh, 0, 1, 128, dst_offset=dr * 384 * 128)
-            wpk = ops.pack_weight(w_ih, 1, 768, nin, 0, nin, 1)
-            d, _ = ops.igemm(dxp, wpk, nin, 1, B * T, 1, 768)
+            if self.conv_mode == "bf16x3":
+                w3 = ops.pack_weight3(w_ih, 1, 768, nin, 0, nin, 1)
+                d, _ = ops.igemm3(dxp, w3, nin, 1, B * T, 1, 768, ((0, 0),))
+            else:
+                wpk = ops.pack_weight(w_ih, 1, 768, nin, 0, nin, 1)
+                d, _ = ops.igemm(dxp, wpk, nin, 1, B * T, 1, 768)
             d = d.view(B, T, nin)
         if not self.train_cnn:
             return
@@ -354,8 +373,13 @@ class CRNN(_FlatModule):
             else:
                 part, G, KP, NP = ops.wgrad(blk["inp"], dy, B, Hh, Ww, cin, co, taps=ops.TAPS3x3)
                 ops.reduce_partials(part, G, 9, KP, NP, cin, co, cw.grad, 1, 9, cin * 9)
-                wd = ops.pack_weight(cw, 9, co, cin, 1, cin * 9, 9)
-                dpool, _ = ops.igemm(dy, wd, cin, B, Hh, Ww, co, taps=[(-a, -b) for a, b in ops.TAPS3x3])
+                flipped = [(-a, -b) for a, b in ops.TAPS3x3]
+                if self.conv_mode == "bf16x3":
+                    wd3 = ops.pack_weight3(cw, 9, co, cin, 1, cin * 9, 9)
+                    dpool, _ = ops.igemm3(dy, wd3, cin, B, Hh, Ww, co, flipped)
+                else:
+                    wd = ops.pack_weight(cw, 9, co, cin, 1, cin * 9, 9)
+                    dpool, _ = ops.igemm(dy, wd, cin, B, Hh, Ww, co, taps=flipped)
 
     def forward(self, x):
         if torch.is_grad_enabled() and self.training:

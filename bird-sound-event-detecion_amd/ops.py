@@ -146,6 +146,40 @@ def igemm(inp, wpk, N, NB, H, W, CIN, taps=((0, 0),), bias=None, out=None, epilo
     return out, stats
 
 
+def pack_weight3(src, ntaps, K, N, s_tap, s_k, s_n):
+    """bf16 hi/lo split weights for igemm3: uint16 (ntaps, K/32, NP, 64)"""
+    NP = round_up(N, 32)
+    dst = torch.empty((ntaps, K // 32, NP, 64), device=src.device, dtype=torch.int16)
+    L.call("bsed_pack_weight3", _fp(_dp(src)), ctypes.c_void_p(dst.data_ptr()), _i(ntaps), _i(K), _i(N), _i(NP),
+           ctypes.c_long(s_tap), ctypes.c_long(s_k), ctypes.c_long(s_n), L.stream())
+    return dst
+
+
+def igemm3(inp, w3, N, NB, H, W, CIN, taps, bias=None, epilogue=EPI_PLAIN):
+    """3x3 conv forward / dgrad on the bf16 matrix cores with split-fp32 operands.  Returns (out, stats or None)."""
+    d = IgemmDesc()
+    TH, TW = tile_for(W)
+    NP = w3.shape[2]
+    dev = inp.device
+    out = torch.empty((NB, H, W, N), device=dev, dtype=torch.float32)
+    ntiles = NB * ((H + TH - 1) // TH) * (W // TW)
+    stats = torch.empty((ntiles, 2, N), device=dev, dtype=torch.float32) if epilogue == EPI_STATS else None
+    d.in_ = _dp(inp); d.w = w3.data_ptr(); d.bias = _p(bias); d.out = _p(out); d.stats = _p(stats)
+    d.in_pitch, d.out_pitch, d.e_pitch = CIN, N, N
+    d.NB, d.H, d.W, d.CIN, d.N, d.NP = NB, H, W, CIN, N, NP
+    d.TH, d.TW = TH, TW
+    d.hh = max(abs(t[0]) for t in taps); d.hw = max(abs(t[1]) for t in taps)
+    d.ntaps = len(taps)
+    for i, (a, b) in enumerate(taps):
+        d.dh[i], d.dw[i] = a, b
+    d.ph = d.pw = 1; d.Hp, d.Wp = H, W
+    d.epilogue = epilogue
+    bn = 128 if NP % 128 == 0 else (64 if NP % 64 == 0 else 32)
+    _launch((f"igemm3_kernel<{bn}, {1 if epilogue == EPI_STATS else 0}>", len(taps), CIN, N, H, W),
+            2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call("bsed_igemm3", ctypes.byref(d), L.stream()))
+    return out, stats
+
+
 def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=None, a_scale=None, a_shift=None,
           in_offset=0, dy_offset=0):
     """Partial slabs of dW; returns (part, G, CINP, NP)."""

@@ -109,6 +109,13 @@ typedef struct BsedIgemmDesc {
 int bsed_igemm(const BsedIgemmDesc* desc /*host*/, void* stream);
 int bsed_igemm_num_tiles(const BsedIgemmDesc* desc /*host*/);
 
+/* Same contraction with split-fp32 operands on the bf16 matrix cores ("bf16x3": a*b ~ a_hi*b_hi + a_hi*b_lo +
+ * a_lo*b_hi, fp32 accumulate, ~1e-5 relative; csrc/igemm3.hip).  BSED_EPI_PLAIN / BSED_EPI_STATS only, CIN a
+ * multiple of 32; desc->w must come from bsed_pack_weight3 (bf16 hi/lo planes, (ntaps, CIN/32, NP, 64) uint16). */
+int bsed_igemm3(const BsedIgemmDesc* desc /*host*/, void* stream);
+int bsed_pack_weight3(const float* src, void* dst, int ntaps, int K, int N, int NP, long s_tap, long s_k, long s_n,
+                      void* stream);
+
 /* dW[tap][k][n] = sum_p in[p + (dh,dw)(tap)][k] * dy[p][n]: persistent workgroups over position tiles
  * write partial slabs part[G][ntaps][CINP][NP]; bsed_reduce_partials sums them into the gradient. */
 typedef struct BsedWgradDesc {
@@ -290,6 +297,8 @@ int bsed_axpy(float* y, const float* x, long n, float a, void* stream);
  * ---------------------------------------------------------------------------------------------- */
 /* C(32,32) = A(32,K) @ B(K,32) through one wave of v_mfma_f32_32x32x2_f32: pins the fragment maps */
 int bsed_selftest_mfma(const float* A, const float* B, float* C, int K, void* stream);
+/* the same through v_mfma_f32_32x32x16_bf16 with bf16x3 split operands (K a multiple of 16) */
+int bsed_selftest_mfma_bf16x3(const float* A, const float* B, float* C, int K, void* stream);
 
 #ifdef __cplusplus
 }

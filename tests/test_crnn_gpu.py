@@ -27,11 +27,13 @@ def _oracle(dropout, seed):
     return crnn, pred
 
 
-def _mine(dropout, ocrnn, opred):
+def _mine(dropout, ocrnn, opred, conv_mode=None):
     from bsed_amd.models import CRNN, Predictor
     kw = dict(co.CRNN_KWARGS)
     kw["dropout"] = dropout
     crnn, pred = CRNN(**kw), Predictor(**co.PREDICTOR_KWARGS)
+    if conv_mode is not None:
+        crnn.conv_mode = conv_mode
     crnn.load_state_dict(ocrnn.state_dict())
     pred.load_state_dict(opred.state_dict())
     return crnn, pred
@@ -63,13 +65,14 @@ def _report(ctx, outs):
     return " ".join(rep)
 
 
+@pytest.mark.parametrize("conv_mode", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("tag", ["small", "R"])
-def test_eval_forward_matches_oracle_and_golden(golden_dir, tag):
+def test_eval_forward_matches_oracle_and_golden(golden_dir, tag, conv_mode):
     g = np.load(os.path.join(golden_dir, f"crnn_{tag}.npz"))
     B, T, seed = (int(v) for v in g["meta"])
     x = torch.from_numpy(seeded.db_like_input(seed + 10, B, T))
     ocrnn, opred = _oracle(0.5, seed)
-    crnn, pred = _mine(0.5, ocrnn, opred)
+    crnn, pred = _mine(0.5, ocrnn, opred, conv_mode)
     ocrnn.eval(); opred.eval(); crnn.eval(); pred.eval()
     outs, enc_ref = _stages(ocrnn, x)
     enc, ctx = crnn.run_forward(x.cuda(), save=True)
@@ -103,14 +106,17 @@ def _grad_check(mine, ref_named, tol=2e-4):
     return bad
 
 
+@pytest.mark.parametrize("conv_mode", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("tag", ["small", "R"])
-def test_train_forward_backward_matches_oracle(golden_dir, tag):
+def test_train_forward_backward_matches_oracle(golden_dir, tag, conv_mode):
+    """both contraction modes meet the SAME bars: split-fp32 operands on the bf16 matrix cores (default) and exact
+    fp32 matrix cores"""
     g = np.load(os.path.join(golden_dir, f"crnn_{tag}.npz"))
     B, T, seed = (int(v) for v in g["meta"])
     x = torch.from_numpy(seeded.db_like_input(seed + 10, B, T))
     y = torch.from_numpy(seeded.strong_targets(seed + 11, B, T // 4))
     ocrnn, opred = _oracle(0.0, seed)
-    crnn, pred = _mine(0.0, ocrnn, opred)
+    crnn, pred = _mine(0.0, ocrnn, opred, conv_mode)
     for m in (ocrnn, opred, crnn, pred):
         m.train()
     outs, _ = _stages(ocrnn, x)          # also advances the oracle's running stats once

@@ -93,6 +93,9 @@ def test_adversarial_train_step_gradients_match_oracle():
     (loss_c + loss_d).backward()
 
     crnn, pred, disc = CRNN(**kw), Predictor(**co.PREDICTOR_KWARGS), Clip_Discriminator()
+    # exact-fp32 contractions here: with B = 2 and 64 frames the discriminator's deeper BatchNorms see a handful of
+    # samples per channel and amplify 1e-5 input perturbations ~100x, which would test conditioning, not wiring
+    crnn.conv_mode = "fp32"
     ocrnn2 = co.CRNN(**kw); seeded.load_seeded(ocrnn2, seed)          # fresh running stats
     odisc2 = co.Clip_Discriminator(); seeded.load_seeded(odisc2, seed + 2)
     crnn.load_state_dict(ocrnn2.state_dict()); pred.load_state_dict(opred.state_dict())

@@ -131,3 +131,44 @@ def test_gru_forward_backward_vs_torch():
     ops.colsum(dgh, B * T, 768, 768, db)
     ref_db = torch.cat([gru.bias_hh_l0.grad, gru.bias_hh_l0_reverse.grad])
     np.testing.assert_allclose(db.cpu().numpy(), ref_db.numpy(), atol=2e-5)
+
+
+def test_mfma_bf16x3_fragment_layout_and_accuracy():
+    from bsed_amd import _lib as L
+    rng = np.random.default_rng(1)
+    K = 128
+    A = rng.standard_normal((32, K)).astype(np.float32)
+    B = rng.standard_normal((K, 32)).astype(np.float32)
+    a, b = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    c = torch.zeros((32, 32), device="cuda")
+    L.call("bsed_selftest_mfma_bf16x3", L.ptr(a), L.ptr(b), L.ptr(c), L.c_int(K), L.stream())
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    err = np.abs(c.cpu().numpy() - ref).max()
+    assert err < 5e-4, err       # ~2e-5 relative on terms of size ~1, sum of 128
+    assert err / np.abs(ref).max() < 3e-5
+
+
+@pytest.mark.parametrize("B,H,W,cin,co", [(2, 21, 16, 64, 128), (1, 19, 8, 128, 128), (2, 70, 4, 128, 128),
+                                          (1, 37, 32, 32, 64), (1, 9, 16, 32, 16)])
+def test_conv3x3_bf16x3_matches_fp64_reference(B, H, W, cin, co):
+    """split-fp32 operands on the bf16 matrix cores: forward (+BN sums) and data gradient within 3e-5 of max|ref|"""
+    from bsed_amd import ops
+    rng = np.random.default_rng(B * 1000 + H)
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((co, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(co).astype(np.float32))
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xg, wg, bg = _nhwc(x).cuda(), w.cuda(), b.cuda()
+    w3 = ops.pack_weight3(wg, 9, cin, co, 1, 9, cin * 9)
+    y, stats = ops.igemm3(xg, w3, co, B, H, W, cin, ops.TAPS3x3, bias=bg, epilogue=ops.EPI_STATS)
+    err = float((y.cpu().double() - _nhwc(ref)).abs().max())
+    assert err < 3e-5 * float(ref.abs().max()), err
+    s = stats.double().sum(0).cpu()
+    np.testing.assert_allclose(s[0].numpy(), ref.sum((0, 2, 3)).numpy(), rtol=1e-3, atol=2e-2)
+    if co % 32 == 0:
+        dy = torch.from_numpy(rng.standard_normal((B, co, H, W)).astype(np.float32))
+        dref = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), padding=1)
+        wd3 = ops.pack_weight3(wg, 9, co, cin, 1, cin * 9, 9)
+        dx, _ = ops.igemm3(_nhwc(dy).cuda(), wd3, cin, B, H, W, co, [(-a, -c) for a, c in ops.TAPS3x3])
+        err = float((dx.cpu().double() - _nhwc(dref)).abs().max())
+        assert err < 3e-5 * float(dref.abs().max()), err
