@@ -21,6 +21,7 @@
 
 #define IG_THREADS 256
 #define IG_TILE_M 128
+#define W3_RD 136  // ushorts per transposed dy row: 128 positions + 8 pad (272 B keeps b128 fragment reads conflict-free)
 
 enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_GLU_POOL = 2, EPI_GLU_BWD = 3, EPI_ADD_STATS2 = 4 };
 
@@ -421,6 +422,178 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(const WgradParams P) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient with split-fp32 operands on the bf16 matrix cores (bf16x3, see igemm3.hip).  K of the GEMM is the
+// position index, so a lane's fragment is 8 POSITIONS of one channel:
+//   * dy is staged TRANSPOSED ([n][128 positions], bf16 hi / lo planes) -> one 16-byte read per fragment;
+//   * the activation patch stays position-major, each element one 32-bit word (hi | lo << 16); the tap-shifted
+//     fragment is gathered with 8 ds_read_b32 (lanes = consecutive channels: conflict-free) and unpacked with
+//     v_perm -- 8 LDS reads replace 8 x 64-cycle fp32 MFMAs by 3 x 32-cycle bf16 MFMAs.
+// ---------------------------------------------------------------------------------------------
+typedef short w3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t w3_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t w3_split(float x) {
+  const uint32_t u = __float_as_uint(x);
+  const uint32_t hi = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+  const float r = x - __uint_as_float(hi << 16);
+  const uint32_t v = __float_as_uint(r);
+  const uint32_t lo = (v + 0x7FFFu + ((v >> 16) & 1u)) >> 16;
+  return hi | (lo << 16);
+}
+
+template <int MAXS, int NW>
+__global__ __launch_bounds__(NW * 64) void wgrad3_kernel(const WgradParams P) {
+  constexpr int NTHR = NW * 64;
+  const BsedWgradDesc& p = P.d;
+  extern __shared__ __align__(16) uint32_t smw[];
+  const int CC = P.CC;
+  const int cz0 = blockIdx.z * CC;
+  uint32_t* Xw = smw;                                                       // [PP][CC] words (hi | lo << 16)
+  unsigned short* DYh = reinterpret_cast<unsigned short*>(smw + P.dy_off);  // [DYW][W3_RD]
+  const int DYW = 32 * P.ntw;
+  unsigned short* DYl = DYh + DYW * W3_RD;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * DYW;
+  const int PW = P.PW;
+  const int ntap_items = P.pack2 ? (p.ntaps + 1) / 2 : p.ntaps;
+  const int nitems = ntap_items * P.nct * P.ntw;
+
+  int xoff[MAXS], boff[MAXS];
+  bool valid[MAXS];
+  f32x16 acc[MAXS];
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) {
+    const int it = wave + NW * s;
+    valid[s] = it < nitems;
+    const int cit = valid[s] ? it % P.nct : 0, rr = valid[s] ? it / P.nct : 0;
+    const int nt = rr % P.ntw, tap = rr / P.ntw;
+    if (P.pack2) {
+      const int ta = 2 * tap, tb = 2 * tap + 1;
+      if (li < 16 || tb >= p.ntaps) xoff[s] = (p.dh[ta] * PW + p.dw[ta]) * CC + li;
+      else xoff[s] = (p.dh[tb] * PW + p.dw[tb]) * CC + (li - 16);
+    } else {
+      xoff[s] = (p.dh[tap] * PW + p.dw[tap]) * CC + cit * 32 + li;
+    }
+    boff[s] = (nt * 32 + li) * W3_RD + 8 * lh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+  }
+
+  for (int tile0 = blockIdx.x; tile0 < P.ntiles; tile0 += gridDim.x) {
+    int tile = tile0;
+    const int tw_i = tile % p.tilesW; tile /= p.tilesW;
+    const int th_i = tile % p.tilesH;
+    const int nb = tile / p.tilesH;
+    const int th0 = th_i * p.TH, tw0 = tw_i * p.TW;
+    const float* inb = p.in + (size_t)nb * p.H * p.W * p.in_pitch;
+    const float* dyb = p.dy + (size_t)nb * p.H * p.W * p.dy_pitch;
+    __syncthreads();
+    // activation patch -> packed split words
+    const int c4n = 1 << P.lgc4;
+    const int x_total = P.PP * c4n;
+    for (int e0 = tid; e0 < x_total; e0 += 4 * NTHR) {
+      float4 v[4];
+      bool okv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * NTHR;
+        const int c4 = e & (c4n - 1), pos = e >> P.lgc4;
+        const int pr = (pos * P.pw_magic) >> 20, pc = pos - pr * PW;
+        const int gh = th0 - p.hh + pr, gw = tw0 - p.hw + pc;
+        const int cg = cz0 + 4 * c4;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        okv[u] = e < x_total && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W && cg < p.CIN;
+        if (okv[u]) v[u] = *reinterpret_cast<const float4*>(inb + ((size_t)gh * p.W + gw) * p.in_pitch + cg);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * NTHR;
+        if (e < x_total) {
+          const int c4 = e & (c4n - 1), pos = e >> P.lgc4;
+          if (p.a_scale && okv[u]) {
+            const int cg = cz0 + 4 * c4;
+            const float4 sc = *reinterpret_cast<const float4*>(p.a_scale + cg);
+            const float4 sh = *reinterpret_cast<const float4*>(p.a_shift + cg);
+            v[u].x = fmaf(v[u].x, sc.x, sh.x); v[u].y = fmaf(v[u].y, sc.y, sh.y);
+            v[u].z = fmaf(v[u].z, sc.z, sh.z); v[u].w = fmaf(v[u].w, sc.w, sh.w);
+          }
+          *reinterpret_cast<uint4*>(Xw + pos * CC + 4 * c4) =
+              make_uint4(w3_split(v[u].x), w3_split(v[u].y), w3_split(v[u].z), w3_split(v[u].w));
+        }
+      }
+    }
+    // dy tile, transposed: thread = (channel n, group of 8 positions)
+    for (int e = tid; e < DYW * 16; e += NTHR) {
+      const int n = e % DYW, g = e / DYW;
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int mm = 8 * g + j;
+        const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
+        f[j] = (gh < p.H && gw < p.W && n0 + n < p.N) ? dyb[((size_t)gh * p.W + gw) * p.dy_pitch + n0 + n] : 0.f;
+      }
+      uint32_t w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = w3_split(f[j]);
+      uint4 hi, lo;
+      hi.x = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u); lo.x = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
+      hi.y = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u); lo.y = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+      hi.z = __builtin_amdgcn_perm(w[5], w[4], 0x05040100u); lo.z = __builtin_amdgcn_perm(w[5], w[4], 0x07060302u);
+      hi.w = __builtin_amdgcn_perm(w[7], w[6], 0x05040100u); lo.w = __builtin_amdgcn_perm(w[7], w[6], 0x07060302u);
+      *reinterpret_cast<uint4*>(DYh + n * W3_RD + 8 * g) = hi;
+      *reinterpret_cast<uint4*>(DYl + n * W3_RD + 8 * g) = lo;
+    }
+    __syncthreads();
+    for (int kp = 0; kp < IG_TILE_M; kp += 16) {
+      int pidx[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int mk = kp + 8 * lh + j;
+        pidx[j] = (((mk >> P.lgTW) + p.hh) * PW + (mk & (p.TW - 1)) + p.hw) * CC;
+      }
+#pragma unroll
+      for (int s = 0; s < MAXS; ++s) {
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = Xw[pidx[j] + xoff[s]];
+        w3_u32x4 ah, al;
+        ah[0] = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u); al[0] = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
+        ah[1] = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u); al[1] = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+        ah[2] = __builtin_amdgcn_perm(w[5], w[4], 0x05040100u); al[2] = __builtin_amdgcn_perm(w[5], w[4], 0x07060302u);
+        ah[3] = __builtin_amdgcn_perm(w[7], w[6], 0x05040100u); al[3] = __builtin_amdgcn_perm(w[7], w[6], 0x07060302u);
+        const w3_bf16x8 a_hi = __builtin_bit_cast(w3_bf16x8, ah), a_lo = __builtin_bit_cast(w3_bf16x8, al);
+        const w3_bf16x8 b_hi = *reinterpret_cast<const w3_bf16x8*>(DYh + boff[s] + kp);
+        const w3_bf16x8 b_lo = *reinterpret_cast<const w3_bf16x8*>(DYl + boff[s] + kp);
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[s], 0, 0, 0);
+      }
+    }
+  }
+  const int NPo = gridDim.y * DYW;
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) {
+    if (valid[s]) {
+      const int it = wave + NW * s;
+      const int cit = it % P.nct, rr = it / P.nct;
+      const int nt = rr % P.ntw, tap = rr / P.ntw;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int ci = cz0 + cit * 32 + crow(r, lh), tp = tap;
+        if (P.pack2) {
+          const int row = crow(r, lh);
+          tp = 2 * tap + (row >> 4);
+          ci = row & 15;
+          if (tp >= p.ntaps) continue;
+        }
+        p.part[(((size_t)blockIdx.x * p.ntaps + tp) * p.CINP + ci) * NPo + n0 + nt * 32 + li] = acc[s][r];
+      }
+    }
+  }
+}
+
 // dst[tap*s_tap + k*s_k + n*s_n] (+)= sum_g part[g][tap][k][n]
 __global__ void reduce_partials_kernel(const float* __restrict__ part, int G, int ntaps, int KP, int NP, int K,
                                        int N, float* __restrict__ dst, long s_tap, long s_k, long s_n,
@@ -574,7 +747,7 @@ static int launch_wgrad(const WgradParams& P, dim3 grid, size_t smem, hipStream_
 }
 
 // shape checks + derived launch geometry shared by bsed_wgrad and bsed_wgrad_auto_g
-static int wgrad_prepare(const BsedWgradDesc* desc, WgradParams& P, size_t& smem, dim3& grid_yz) {
+static int wgrad_prepare(const BsedWgradDesc* desc, WgradParams& P, size_t& smem, dim3& grid_yz, int mode3 = 0) {
   BSED_CHECK_ARG(desc, "bsed_wgrad: null descriptor");
   P.d = *desc;
   BsedWgradDesc& d = P.d;
@@ -602,7 +775,7 @@ static int wgrad_prepare(const BsedWgradDesc* desc, WgradParams& P, size_t& smem
   P.lgc4 = ilog2_exact(P.CC / 4);
   P.nct = P.CC / 32;
   P.pack2 = (d.CIN <= 16 && d.CINP == 32 && d.ntaps > 1) ? 1 : 0;
-  P.dy_off = (P.PP * (P.CC + 1) + 3) & ~3;
+  P.dy_off = mode3 ? P.PP * P.CC : ((P.PP * (P.CC + 1) + 3) & ~3);  // in 4-byte words
   P.pw_magic = ((1 << 20) + P.PW - 1) / P.PW;
   for (int pos = 0; pos < P.PP; ++pos)
     BSED_CHECK_ARG(((pos * P.pw_magic) >> 20) == pos / P.PW, "bsed_wgrad: internal: magic division fails for PW=%d", P.PW);
@@ -612,12 +785,14 @@ static int wgrad_prepare(const BsedWgradDesc* desc, WgradParams& P, size_t& smem
   // staged once per 64 output channels and the per-CU load rate stops being the limiter)
   P.ntw = 1;
   for (int cand = 4; cand >= 2; cand >>= 1) {
-    const size_t need = ((size_t)P.dy_off + IG_TILE_M * 32 * cand) * sizeof(float);
+    const size_t need = mode3 ? (size_t)P.dy_off * 4 + (size_t)2 * 32 * cand * W3_RD * 2
+                              : ((size_t)P.dy_off + IG_TILE_M * 32 * cand) * sizeof(float);
     const size_t budget = d.ntaps == 1 ? 160 * 1024 : 80 * 1024;
     const int tap_items = P.pack2 ? (d.ntaps + 1) / 2 : d.ntaps;
     if (d.NP % (32 * cand) == 0 && tap_items * P.nct * cand <= 36 && need <= budget) { P.ntw = cand; break; }
   }
-  smem = ((size_t)P.dy_off + IG_TILE_M * 32 * P.ntw) * sizeof(float);
+  smem = mode3 ? (size_t)P.dy_off * 4 + (size_t)2 * 32 * P.ntw * W3_RD * 2
+               : ((size_t)P.dy_off + IG_TILE_M * 32 * P.ntw) * sizeof(float);
   BSED_CHECK_ARG(smem <= 160 * 1024, "bsed_wgrad: tile needs %zu B of LDS", smem);
   const long ntiles = (long)d.NB * d.tilesH * d.tilesW;
   BSED_CHECK_ARG(ntiles < (1L << 31), "bsed_wgrad: too many tiles");
@@ -687,6 +862,61 @@ extern "C" int bsed_wgrad(const BsedWgradDesc* desc, void* stream) {
   if (slots <= 9) return launch_wgrad<9, 4>(P, grid, smem, s);
   bsed_set_error("bsed_wgrad: %d work items per workgroup exceed the 36 supported", nitems);
   return BSED_ERR_ARG;
+}
+
+
+template <int MAXS, int NW>
+static int launch_wgrad3(const WgradParams& P, dim3 grid, size_t smem, hipStream_t s) {
+  static bool done = false;
+  if (!done) {
+    BSED_HIP(hipFuncSetAttribute((const void*)wgrad3_kernel<MAXS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+  }
+  hipLaunchKernelGGL((wgrad3_kernel<MAXS, NW>), grid, dim3(NW * 64), smem, s, P);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_wgrad3_auto_g(const BsedWgradDesc* desc) {
+  WgradParams P;
+  size_t smem;
+  dim3 gyz;
+  if (wgrad_prepare(desc, P, smem, gyz, 1) != BSED_OK) return -1;
+  const long slots = smem <= 80 * 1024 ? 512 : 256;
+  const long want = std::max<long>(1, slots / ((long)gyz.y * gyz.z));
+  return (int)std::max<long>(1, std::min<long>(want, P.ntiles));
+}
+
+extern "C" int bsed_wgrad3_variant(const BsedWgradDesc* desc) {
+  WgradParams P;
+  size_t smem;
+  dim3 gyz;
+  if (wgrad_prepare(desc, P, smem, gyz, 1) != BSED_OK) return -1;
+  return wgrad_variant(P);
+}
+
+extern "C" int bsed_wgrad3(const BsedWgradDesc* desc, void* stream) {
+  WgradParams P;
+  size_t smem;
+  dim3 gyz;
+  int rc = wgrad_prepare(desc, P, smem, gyz, 1);
+  if (rc != BSED_OK) return rc;
+  BsedWgradDesc& d = P.d;
+  BSED_CHECK_ARG(d.in && d.dy && d.part, "bsed_wgrad3: null tensor");
+  BSED_CHECK_ARG(d.G > 0 && d.G <= P.ntiles, "bsed_wgrad3: G (%d) must be in 1..%d tiles", d.G, P.ntiles);
+  dim3 grid((unsigned)d.G, gyz.y, gyz.z);
+  hipStream_t s = (hipStream_t)stream;
+  const int v = wgrad_variant(P), maxs = v / 16, nw = v % 16;
+  if (nw == 8) {
+    if (maxs == 2) return launch_wgrad3<2, 8>(P, grid, smem, s);
+    if (maxs == 3) return launch_wgrad3<3, 8>(P, grid, smem, s);
+    return launch_wgrad3<5, 8>(P, grid, smem, s);
+  }
+  if (maxs == 1) return launch_wgrad3<1, 4>(P, grid, smem, s);
+  if (maxs == 2) return launch_wgrad3<2, 4>(P, grid, smem, s);
+  if (maxs == 3) return launch_wgrad3<3, 4>(P, grid, smem, s);
+  if (maxs == 5) return launch_wgrad3<5, 4>(P, grid, smem, s);
+  return launch_wgrad3<9, 4>(P, grid, smem, s);
 }
 
 extern "C" int bsed_reduce_partials(const float* part, int G, int ntaps, int KP, int NP, int K, int N, float* dst,

@@ -180,9 +180,15 @@ def igemm3(inp, w3, N, NB, H, W, CIN, taps, bias=None, epilogue=EPI_PLAIN):
     return out, stats
 
 
+WGRAD_MODE = {"mode": None}  # None = follow BSED_CONV_MODE; "fp32" / "bf16x3" force one
+
+
 def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=None, a_scale=None, a_shift=None,
-          in_offset=0, dy_offset=0):
-    """Partial slabs of dW; returns (part, G, CINP, NP)."""
+          in_offset=0, dy_offset=0, mode=None):
+    """Partial slabs of dW; returns (part, G, CINP, NP).  mode "bf16x3" = split-fp32 operands on the bf16 cores."""
+    import os
+    mode = mode or WGRAD_MODE["mode"] or os.environ.get("BSED_CONV_MODE", "bf16x3")
+    sfx = "3" if mode == "bf16x3" else ""
     d = WgradDesc()
     TH, TW = tile_for(W)
     CINP, NP = round_up(CIN, 32), round_up(N, 32)
@@ -197,14 +203,14 @@ def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=Non
     d.ntaps = len(taps)
     for i, (a, b) in enumerate(taps):
         d.dh[i], d.dw[i] = a, b
-    G = L.lib().bsed_wgrad_auto_g(ctypes.byref(d))
+    G = getattr(L.lib(), f"bsed_wgrad{sfx}_auto_g")(ctypes.byref(d))
     if G <= 0:
         raise L.BsedError("bsed_wgrad_auto_g: " + L.lib().bsed_last_error().decode())
     part = torch.empty((G, len(taps), CINP, NP), device=inp.device, dtype=torch.float32)
     d.part, d.G = _p(part), G
-    var = L.lib().bsed_wgrad_variant(ctypes.byref(d))
-    _launch((f"wgrad_kernel<{var // 16}, {var % 16}>", len(taps), CIN, N, H, W), 2.0 * NB * H * W * len(taps) * CIN * N,
-            lambda: L.call("bsed_wgrad", ctypes.byref(d), L.stream()))
+    var = getattr(L.lib(), f"bsed_wgrad{sfx}_variant")(ctypes.byref(d))
+    _launch((f"wgrad{sfx}_kernel<{var // 16}, {var % 16}>", len(taps), CIN, N, H, W),
+            2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call(f"bsed_wgrad{sfx}", ctypes.byref(d), L.stream()))
     return part, G, CINP, NP
 
 

@@ -135,6 +135,11 @@ int bsed_wgrad(const BsedWgradDesc* desc /*host*/, void* stream);
 int bsed_wgrad_auto_g(const BsedWgradDesc* desc /*host*/);
 /* template instance bsed_wgrad launches for this shape, as MAXS*16 + NW (labels profiles and bench lines) */
 int bsed_wgrad_variant(const BsedWgradDesc* desc /*host*/);
+/* the same contraction with split-fp32 operands on the bf16 matrix cores (bf16x3, ~1e-5 relative): dy staged
+ * transposed, activation fragments gathered per tap.  Same descriptor, same partial-slab layout. */
+int bsed_wgrad3(const BsedWgradDesc* desc /*host*/, void* stream);
+int bsed_wgrad3_auto_g(const BsedWgradDesc* desc /*host*/);
+int bsed_wgrad3_variant(const BsedWgradDesc* desc /*host*/);
 /* dst[tap*s_tap + k*s_k + n*s_n] (+)= sum_g part[g][tap][k][n]   (k < K, n < N) */
 int bsed_reduce_partials(const float* part, int G, int ntaps, int KP, int NP, int K, int N, float* dst,
                          long s_tap, long s_k, long s_n, int accumulate, void* stream);

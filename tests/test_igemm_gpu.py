@@ -47,13 +47,14 @@ def test_conv3x3_forward_stats_and_dgrad(B, H, W, cin, co):
     wd = ops.pack_weight(wg, 9, co, cin, 1, cin * 9, 9)
     dx, _ = ops.igemm(_nhwc(dy).cuda(), wd, cin, B, H, W, co, taps=[(-a, -c) for a, c in ops.TAPS3x3])
     np.testing.assert_allclose(dx.cpu().double().numpy(), _nhwc(dref).numpy(), atol=5e-5)
-    # weight gradient
+    # weight gradient: exact fp32 matrix cores and split-fp32 (bf16x3) operands
     wref = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=1)
-    part, G, KP, NP = ops.wgrad(xg, _nhwc(dy).cuda(), B, H, W, cin, co, taps=ops.TAPS3x3)
-    dw = torch.zeros_like(wg)
-    ops.reduce_partials(part, G, 9, KP, NP, cin, co, dw, 1, 9, cin * 9)
-    err = float((dw.cpu().double() - wref).norm() / wref.norm())
-    assert err < 1e-5, err
+    for mode, tol in (("fp32", 1e-5), ("bf16x3", 4e-5)):
+        part, G, KP, NP = ops.wgrad(xg, _nhwc(dy).cuda(), B, H, W, cin, co, taps=ops.TAPS3x3, mode=mode)
+        dw = torch.zeros_like(wg)
+        ops.reduce_partials(part, G, 9, KP, NP, cin, co, dw, 1, 9, cin * 9)
+        err = float((dw.cpu().double() - wref).norm() / wref.norm())
+        assert err < tol, (mode, err)
 
 
 @pytest.mark.parametrize("M,K,N", [(300, 128, 768), (129, 256, 768), (1000, 768, 128), (77, 768, 256)])
@@ -71,12 +72,13 @@ def test_plain_gemm_and_tn_wgrad(M, K, N):
     if K > 256:
         return  # weight gradients only ever contract over <= 256 input features on this path
     dy = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32))
-    part, G, KP, NP = ops.wgrad(xg, dy.cuda(), 1, M, 1, K, N)
-    dw = torch.zeros_like(wg)
-    ops.reduce_partials(part, G, 1, KP, NP, K, N, dw, 0, 1, K)
     wref = dy.double().T @ x.double()
-    err = float((dw.cpu().double() - wref).norm() / wref.norm())
-    assert err < 1e-5, err
+    for mode, tol in (("fp32", 1e-5), ("bf16x3", 4e-5)):
+        part, G, KP, NP = ops.wgrad(xg, dy.cuda(), 1, M, 1, K, N, mode=mode)
+        dw = torch.zeros_like(wg)
+        ops.reduce_partials(part, G, 1, KP, NP, K, N, dw, 0, 1, K)
+        err = float((dw.cpu().double() - wref).norm() / wref.norm())
+        assert err < tol, (mode, err)
 
 
 def test_shifted_tap_wgrad_matches_gru_hidden_gradient_form():
@@ -87,9 +89,9 @@ def test_shifted_tap_wgrad_matches_gru_hidden_gradient_form():
     out = torch.from_numpy(rng.standard_normal((B, T, 256)).astype(np.float32))
     dgh = torch.from_numpy(rng.standard_normal((B, T, 768)).astype(np.float32))
     og, dg = out.cuda(), dgh.cuda()
-    for dr in range(2):
+    for dr, mode in ((0, "fp32"), (1, "fp32"), (0, "bf16x3"), (1, "bf16x3")):
         part, G, KP, NP = ops.wgrad(og, dg, B, T, 1, 128, 384, taps=((-1 if dr == 0 else 1, 0),), in_pitch=256,
-                                    dy_pitch=768, in_offset=dr * 128, dy_offset=dr * 384)
+                                    dy_pitch=768, in_offset=dr * 128, dy_offset=dr * 384, mode=mode)
         dw = torch.zeros((384, 128), device="cuda")
         ops.reduce_partials(part, G, 1, KP, NP, 128, 384, dw, 0, 1, 128)
         h = out[:, :, dr * 128:(dr + 1) * 128].double()
@@ -100,7 +102,7 @@ def test_shifted_tap_wgrad_matches_gru_hidden_gradient_form():
             hp[:, :-1] = h[:, 1:]
         ref = torch.einsum("btj,btk->jk", dgh[:, :, dr * 384:(dr + 1) * 384].double(), hp)
         err = float((dw.cpu().double() - ref).norm() / ref.norm())
-        assert err < 1e-5, (dr, err)
+        assert err < (1e-5 if mode == "fp32" else 4e-5), (dr, mode, err)
 
 
 def test_gru_forward_backward_vs_torch():
