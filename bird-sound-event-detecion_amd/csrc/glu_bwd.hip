@@ -34,18 +34,24 @@ struct GluBwdParams {
 
 __device__ __forceinline__ int crow2(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
-template <int C>
-__global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdParams P) {
-  constexpr int NT = C / 32;
+// NW = 8 (C = 128 only): the eight waves split the channel tiles in two halves, so every SIMD hosts two waves and one
+// wave's staging / epilogue latency hides behind the other's MFMAs (the 148 KB of LDS allow a single workgroup per CU).
+template <int C, int NW>
+__global__ __launch_bounds__(NW * 64) void glu_bwd_fused_kernel(const GluBwdParams P) {
+  constexpr int NTHR = NW * 64;
+  constexpr int NTA = C / 32;                    // 32-wide channel tiles in total
+  constexpr int NT = NTA / (NW / 4);             // ... per wave
   constexpr int XP = C + 1;
-  constexpr int KSPLIT = NT >= 4 ? 1 : 4 / NT;  // waves that share one dW row-tile split the positions
+  constexpr int KSPLIT = NTA >= 4 ? 1 : 4 / NTA; // waves that share one dW row-tile split the positions
   constexpr bool RES = C <= 32;                  // both weight matrices stay resident in LDS: no slab traffic / barriers
   extern __shared__ __align__(16) float smem[];
   float* Xs = smem;                 // [128][XP]  BatchNorm output
   float* Ds = Xs + GB_M * XP;       // [128][XP]  d_lin
   float* Bs = Ds + GB_M * XP;       // [32][C]    weight slab   (RES: [2][C][C] = W^T then W, loaded once)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  const int m = wave * 32 + li;
+  const int rbase = (wave & 3) * 32;             // the 32 tile rows (positions) of this wave
+  const int cbase = (wave >> 2) * NT * 32;       // first channel of this wave's column tiles
+  const int m = rbase + li;
   const int sph = P.ph >> 1, spw = P.pw >> 1;
   const float inv_pool = 1.0f / (float)(P.ph * P.pw);
   const uint32_t dkey = drop_key(P.rng_stream, P.seed), dthr = drop_threshold(P.drop_p);
@@ -55,15 +61,15 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
   f32x16 acc3[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    bias[j] = P.bias[32 * j + li];
+    bias[j] = P.bias[cbase + 32 * j + li];
     sdb[j] = 0.f; sgs[j] = 0.f; sgy[j] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc3[j][r] = 0.f;
   }
-  const int nt3 = wave % NT, kq = wave / NT;     // GEMM3 role of this wave
+  const int nt3 = NW == 8 ? (wave & 3) : wave % NTA, kq = NW == 8 ? 0 : wave / NTA;  // GEMM3 role of this wave
   constexpr int KR = GB_M / KSPLIT;
   if (RES) {
-    for (int e = tid; e < C * C / 4; e += GB_THREADS) {
+    for (int e = tid; e < C * C / 4; e += NTHR) {
       reinterpret_cast<float4*>(Bs)[e] = reinterpret_cast<const float4*>(P.wfwd)[e];
       reinterpret_cast<float4*>(Bs + C * C)[e] = reinterpret_cast<const float4*>(P.wbwd)[e];
     }
@@ -78,12 +84,12 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
     __syncthreads();  // every wave is done with Xs/Ds of the previous tile (GEMM3)
     // ---- stage xn = y*scale + shift
     constexpr int C4 = C / 4;
-    for (int e0 = tid; e0 < GB_M * C4; e0 += 4 * GB_THREADS) {
+    for (int e0 = tid; e0 < GB_M * C4; e0 += 4 * NTHR) {
       float4 v[4];
       bool okv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int e = e0 + u * GB_THREADS;
+        const int e = e0 + u * NTHR;
         const int c4 = e % C4, mm = e / C4;
         const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (P.TW - 1));
         okv[u] = gh < P.H && gw < P.W;
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int e = e0 + u * GB_THREADS;
+        const int e = e0 + u * NTHR;
         const int c4 = e % C4, mm = e / C4;
         if (okv[u]) {
           const float4 sc = *reinterpret_cast<const float4*>(P.scale + 4 * c4);
@@ -115,14 +121,14 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
     for (int k0 = 0; k0 < C; k0 += 32) {
       if (!RES) {
         __syncthreads();
-        for (int e = tid; e < 32 * C4; e += GB_THREADS) {
+        for (int e = tid; e < 32 * C4; e += NTHR) {
           const int k = e / C4, n4 = e % C4;
           *reinterpret_cast<float4*>(Bs + k * C + 4 * n4) = *reinterpret_cast<const float4*>(P.wfwd + (size_t)(k0 + k) * C + 4 * n4);
         }
         __syncthreads();
       }
       const float* arow = Xs + m * XP + k0 + lh;
-      const float* brow = (RES ? Bs + k0 * C : Bs) + lh * C + li;
+      const float* brow = (RES ? Bs + k0 * C : Bs) + lh * C + cbase + li;
 #pragma unroll 4
       for (int kk = 0; kk < 32; kk += 2) {
         const float a = arow[kk];
@@ -140,14 +146,14 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
       size_t posv[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const int mm = wave * 32 + crow2(rg * 4 + rr, lh);
+        const int mm = rbase + crow2(rg * 4 + rr, lh);
         const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (P.TW - 1));
         const bool pok = gh < P.H && gw < P.W;
         const int gph = gh >> sph, gpw = gw >> spw;
         const bool pooled_ok = pok && gph < P.Hp && gpw < P.Wp;
         mmv[rr] = mm; okr[rr] = pok;
         posv[rr] = ((size_t)nb * P.H + gh) * P.W + gw;
-        const float* dprow = P.dpool + (((size_t)nb * P.Hp + gph) * P.Wp + gpw) * C + li;
+        const float* dprow = P.dpool + (((size_t)nb * P.Hp + gph) * P.Wp + gpw) * C + cbase + li;
 #pragma unroll
         for (int j = 0; j < NT; ++j) dv[rr][j] = pooled_ok ? dprow[32 * j] : 0.f;
       }
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
         const int r = rg * 4 + rr;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const int n = 32 * j + li;
+          const int n = cbase + 32 * j + li;
           float dl = 0.f, tt = 0.f;
           if (okr[rr]) {
             const float xn = Xs[mmv[rr] * XP + n];
@@ -177,14 +183,14 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
     for (int k0 = 0; k0 < C; k0 += 32) {
       if (!RES) {
         __syncthreads();
-        for (int e = tid; e < 32 * C4; e += GB_THREADS) {
+        for (int e = tid; e < 32 * C4; e += NTHR) {
           const int k = e / C4, n4 = e % C4;
           *reinterpret_cast<float4*>(Bs + k * C + 4 * n4) = *reinterpret_cast<const float4*>(P.wbwd + (size_t)(k0 + k) * C + 4 * n4);
         }
         __syncthreads();
       }
       const float* arow = Ds + m * XP + k0 + lh;
-      const float* brow = (RES ? Bs + C * C + k0 * C : Bs) + lh * C + li;
+      const float* brow = (RES ? Bs + C * C + k0 * C : Bs) + lh * C + cbase + li;
 #pragma unroll 4
       for (int kk = 0; kk < 32; kk += 2) {
         const float a = arow[kk];
@@ -201,12 +207,12 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
       size_t posv[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const int mm = wave * 32 + crow2(rg * 4 + rr, lh);
+        const int mm = rbase + crow2(rg * 4 + rr, lh);
         const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (P.TW - 1));
         okr[rr] = gh < P.H && gw < P.W;
         posv[rr] = ((size_t)nb * P.H + gh) * P.W + gw;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) yv[rr][j] = okr[rr] ? P.y[posv[rr] * C + 32 * j + li] : 0.f;
+        for (int j = 0; j < NT; ++j) yv[rr][j] = okr[rr] ? P.y[posv[rr] * C + cbase + 32 * j + li] : 0.f;
       }
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             const float gv = acc[j][r];
-            P.g[posv[rr] * C + 32 * j + li] = gv;
+            P.g[posv[rr] * C + cbase + 32 * j + li] = gv;
             sgs[j] += gv;
             sgy[j] = fmaf(gv, yv[rr][j], sgy[j]);
           }
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
     if (RES) __syncthreads();
     {
       const float* abase = Ds + nt3 * 32 + li;
-      const float* bbase = Xs + li;
+      const float* bbase = Xs + cbase + li;
 #pragma unroll 2
       for (int kp = kq * KR; kp < (kq + 1) * KR; kp += 2) {
         const int mk = kp + lh;
@@ -247,23 +253,23 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = nt3 * 32 + crow2(r, lh);
-      P.part_dw[(((size_t)blockIdx.x * KSPLIT + kq) * C + n) * C + 32 * j + li] = acc3[j][r];
+      P.part_dw[(((size_t)blockIdx.x * KSPLIT + kq) * C + n) * C + cbase + 32 * j + li] = acc3[j][r];
     }
   __syncthreads();
-  float* red = smem;  // [4 waves][3][C]
+  float* red = smem;  // [4 row groups][3][C]; wave (row group, half) owns the columns of its half
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const float a = sdb[j] + __shfl_xor(sdb[j], 32, 64);
     const float b = sgs[j] + __shfl_xor(sgs[j], 32, 64);
     const float c = sgy[j] + __shfl_xor(sgy[j], 32, 64);
     if (lh == 0) {
-      red[(wave * 3 + 0) * C + 32 * j + li] = a;
-      red[(wave * 3 + 1) * C + 32 * j + li] = b;
-      red[(wave * 3 + 2) * C + 32 * j + li] = c;
+      red[((wave & 3) * 3 + 0) * C + cbase + 32 * j + li] = a;
+      red[((wave & 3) * 3 + 1) * C + cbase + 32 * j + li] = b;
+      red[((wave & 3) * 3 + 2) * C + cbase + 32 * j + li] = c;
     }
   }
   __syncthreads();
-  for (int e = tid; e < 3 * C; e += GB_THREADS) {
+  for (int e = tid; e < 3 * C; e += NTHR) {
     const int which = e / C, n = e % C;
     const float s = red[(0 * 3 + which) * C + n] + red[(1 * 3 + which) * C + n] + red[(2 * 3 + which) * C + n] +
                     red[(3 * 3 + which) * C + n];
@@ -276,15 +282,15 @@ __global__ __launch_bounds__(GB_THREADS) void glu_bwd_fused_kernel(const GluBwdP
   }
 }
 
-template <int C>
+template <int C, int NW>
 static int launch_glu_bwd(const GluBwdParams& P, int G, hipStream_t s) {
   const size_t smem = ((size_t)2 * GB_M * (C + 1) + (C <= 32 ? 2 * C * C : 32 * C)) * sizeof(float);
   static bool done = false;
   if (!done) {
-    BSED_HIP(hipFuncSetAttribute((const void*)glu_bwd_fused_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    BSED_HIP(hipFuncSetAttribute((const void*)glu_bwd_fused_kernel<C, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
-  hipLaunchKernelGGL((glu_bwd_fused_kernel<C>), dim3(G), dim3(GB_THREADS), smem, s, P);
+  hipLaunchKernelGGL((glu_bwd_fused_kernel<C, NW>), dim3(G), dim3(NW * 64), smem, s, P);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }
@@ -314,7 +320,7 @@ extern "C" int bsed_glu_bwd_fused(const float* y, const float* scale, const floa
   P.ph = ph; P.pw = pw; P.Hp = H / ph; P.Wp = W / pw;
   P.drop_p = drop_p; P.rng_stream = rng_stream; P.seed = seed;
   hipStream_t s = (hipStream_t)stream;
-  if (C == 128) return launch_glu_bwd<128>(P, G, s);
-  if (C == 64) return launch_glu_bwd<64>(P, G, s);
-  return launch_glu_bwd<32>(P, G, s);
+  if (C == 128) return launch_glu_bwd<128, 8>(P, G, s);
+  if (C == 64) return launch_glu_bwd<64, 4>(P, G, s);
+  return launch_glu_bwd<32, 4>(P, G, s);
 }

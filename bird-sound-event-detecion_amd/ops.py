@@ -288,7 +288,7 @@ def glu_bwd_fused(y, scale, shift, wfwd, w, bias, dpool, B, H, W, C, pool, drop_
     part_db = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
     part_st = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
     flops = 3 * 2.0 * B * H * W * C * C
-    _launch((f"glu_bwd_fused_kernel<{C}>", 1, C, C, H, W), flops,
+    _launch((f"glu_bwd_fused_kernel<{C}, {8 if C == 128 else 4}>", 1, C, C, H, W), flops,
             lambda: L.call("bsed_glu_bwd_fused", L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(wfwd), _fp(_dp(w)),
                            _fp(_dp(bias)), L.ptr(dpool), L.ptr(g), L.ptr(part_dw), L.ptr(part_db), L.ptr(part_st),
                            _i(G), _i(B), _i(H), _i(W), _i(C), _i(TH), _i(TW), _i(ph), _i(pw), ctypes.c_float(drop_p),
