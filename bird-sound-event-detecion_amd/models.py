@@ -285,7 +285,7 @@ class CRNN(_FlatModule):
             else:
                 wpk = ops.pack_weight(w_ih, 1, nin, 768, 0, 1, nin)
                 xp, _ = ops.igemm(seq, wpk, 768, 1, B * T, 1, nin, bias=b_ih)
-            out, gates = ops.gru_fwd(xp.view(B, T, 768), w_hh, b_hh, B, T, save_gates=save)
+            out, gates = ops.gru_fwd(xp.view(B, T, 768), w_hh, b_hh, B, T, save_gates=save, mode=self.conv_mode)
             layers.append(dict(inp=seq, out=out, gates=gates))
             seq = out
         enc = ops.dropout(seq, drop, 200, self.seed) if drop > 0 else seq
@@ -305,7 +305,7 @@ class CRNN(_FlatModule):
             nin, w_ih, w_hh, b_ih, b_hh = self._rnn_views(l)
             g_wih, g_whh, g_bih, g_bhh = self._rnn_grads(l)
             lay = ctx["layers"][l]
-            dxp, dgh = ops.gru_bwd(d, lay["out"], lay["gates"], w_hh, B, T)
+            dxp, dgh = ops.gru_bwd(d, lay["out"], lay["gates"], w_hh, B, T, mode=self.conv_mode)
             ops.colsum(dxp, B * T, 768, 768, g_bih)
             ops.colsum(dgh, B * T, 768, 768, g_bhh)
             part, G, KP, NP = ops.wgrad(lay["inp"], dxp, 1, B * T, 1, nin, 768)

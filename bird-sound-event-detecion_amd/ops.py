@@ -342,23 +342,31 @@ def dropout(x, p, rng_stream, seed):
 
 
 def gru_rows(B):
-    """rows per workgroup so that (B/R) x 2 directions fills the 256 CUs"""
+    """rows per workgroup of the fp32 register kernels so that (B/R) x 2 directions fills the 256 CUs"""
     return 1 if B * 2 <= 256 else 2
 
 
-def gru_fwd(xp, w_hh, b_hh, B, T, save_gates):
+def gru_fwd(xp, w_hh, b_hh, B, T, save_gates, mode="fp32"):
     out = torch.empty((B, T, 256), device=xp.device, dtype=torch.float32)
     gates = torch.empty((B, T, 2, 4, 128), device=xp.device, dtype=torch.float32) if save_gates else None
-    L.call("bsed_gru_fwd", L.ptr(xp), _fp(_dp(w_hh)), _fp(_dp(b_hh)), L.ptr(out), _fp(_p(gates)), _i(B), _i(T),
-           _i(gru_rows(B)), L.stream())
+    if mode == "bf16x3":  # matrix-core recurrence, split-fp32 operands
+        L.call("bsed_gru_fwd3", L.ptr(xp), _fp(_dp(w_hh)), _fp(_dp(b_hh)), L.ptr(out), _fp(_p(gates)), _i(B), _i(T),
+               L.stream())
+    else:
+        L.call("bsed_gru_fwd", L.ptr(xp), _fp(_dp(w_hh)), _fp(_dp(b_hh)), L.ptr(out), _fp(_p(gates)), _i(B), _i(T),
+               _i(gru_rows(B)), L.stream())
     return out, gates
 
 
-def gru_bwd(dout, out, gates, w_hh, B, T):
+def gru_bwd(dout, out, gates, w_hh, B, T, mode="fp32"):
     dxp = torch.empty((B, T, 768), device=dout.device, dtype=torch.float32)
     dgh = torch.empty((B, T, 768), device=dout.device, dtype=torch.float32)
-    L.call("bsed_gru_bwd", L.ptr(dout), L.ptr(out), L.ptr(gates), _fp(_dp(w_hh)), L.ptr(dxp), L.ptr(dgh), _i(B), _i(T),
-           _i(gru_rows(B)), L.stream())
+    if mode == "bf16x3":
+        L.call("bsed_gru_bwd3", L.ptr(dout), L.ptr(out), L.ptr(gates), _fp(_dp(w_hh)), L.ptr(dxp), L.ptr(dgh), _i(B),
+               _i(T), L.stream())
+    else:
+        L.call("bsed_gru_bwd", L.ptr(dout), L.ptr(out), L.ptr(gates), _fp(_dp(w_hh)), L.ptr(dxp), L.ptr(dgh), _i(B),
+               _i(T), _i(gru_rows(B)), L.stream())
     return dxp, dgh
 
 

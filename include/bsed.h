@@ -239,6 +239,12 @@ int bsed_gru_fwd(const float* xp, const float* w_hh, const float* b_hh, float* o
 /* BPTT: dxp = d(x-side pre-activations) (B,T,768), dgh = d(h-side pre-activations) (B,T,768) */
 int bsed_gru_bwd(const float* dout, const float* out, const float* gates, const float* w_hh, float* dxp,
                  float* dgh, int B, int T, int rows_per_wg, void* stream);
+/* The same recurrence with h @ W_hh^T of every step on the bf16 matrix cores with split-fp32 operands (4 batch rows
+ * per workgroup; the default in the bf16x3 contraction mode).  Same tensors, same layouts, same reference lines. */
+int bsed_gru_fwd3(const float* xp, const float* w_hh, const float* b_hh, float* out, float* gates, int B, int T,
+                  void* stream);
+int bsed_gru_bwd3(const float* dout, const float* out, const float* gates, const float* w_hh, float* dxp,
+                  float* dgh, int B, int T, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Predictor head + losses (csrc/head.hip); replaces Predictor.forward (src/models/CRNN_GRL.py:441-460)

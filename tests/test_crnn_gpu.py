@@ -407,3 +407,38 @@ def test_gru_two_rows_per_workgroup_with_odd_batch():
     wd = ops.pack_weight(w_ih, 1, 768, 128, 0, 128, 1)
     dx, _ = ops.igemm(dxp, wd, 128, 1, B * T, 1, 768)
     np.testing.assert_allclose(dx.view(B, T, 128).cpu().numpy(), x.grad.numpy(), atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(3, 40), (37, 63)])
+def test_gru_matrix_core_recurrence_vs_torch(B, T):
+    """bsed_gru_fwd3/bwd3: h @ W_hh^T of every step on the bf16 matrix cores with split-fp32 operands (the default in
+    bf16x3 mode), 4 batch rows per workgroup.  B = 37 leaves 3 idle rows in the last workgroup, T = 63 exercises the
+    dummy half-iteration of the 2x unrolled time loop.  Bars: outputs 2e-5 abs (the logit bar is 1e-4), gradients 1e-4
+    abs on O(1) values."""
+    from bsed_amd import ops
+    torch.manual_seed(2)
+    gru = torch.nn.GRU(128, 128, bidirectional=True, batch_first=True)
+    x = torch.randn(B, T, 128).requires_grad_()
+    ref, _ = gru(x)
+    dout = torch.randn(B, T, 256)
+    ref.backward(dout)
+    sd = gru.state_dict()
+    w_ih = torch.cat([sd["weight_ih_l0"], sd["weight_ih_l0_reverse"]]).cuda()
+    w_hh = torch.cat([sd["weight_hh_l0"], sd["weight_hh_l0_reverse"]]).contiguous().cuda()
+    b_ih = torch.cat([sd["bias_ih_l0"], sd["bias_ih_l0_reverse"]]).cuda()
+    b_hh = torch.cat([sd["bias_hh_l0"], sd["bias_hh_l0_reverse"]]).cuda()
+    wpk = ops.pack_weight(w_ih, 1, 128, 768, 0, 1, 128)
+    xp, _ = ops.igemm(x.detach().cuda(), wpk, 768, 1, B * T, 1, 128, bias=b_ih)
+    out, gates = ops.gru_fwd(xp.view(B, T, 768), w_hh, b_hh, B, T, save_gates=True, mode="bf16x3")
+    assert float((out.cpu() - ref.detach()).abs().max()) < 2e-5
+    out_nosave, _ = ops.gru_fwd(xp.view(B, T, 768), w_hh, b_hh, B, T, save_gates=False, mode="bf16x3")
+    assert torch.equal(out_nosave, out)
+    dxp, dgh = ops.gru_bwd(dout.cuda(), out, gates, w_hh, B, T, mode="bf16x3")
+    wd = ops.pack_weight(w_ih, 1, 768, 128, 0, 128, 1)
+    dx, _ = ops.igemm(dxp, wd, 128, 1, B * T, 1, 768)
+    assert float((dx.view(B, T, 128).cpu() - x.grad).abs().max()) < 1e-4
+    db = torch.zeros(768, device="cuda")
+    ops.colsum(dgh, B * T, 768, 768, db)
+    ref_db = torch.cat([gru.bias_hh_l0.grad, gru.bias_hh_l0_reverse.grad])
+    assert float((db.cpu() - ref_db).abs().max()) < 2e-4 * max(1.0, float(ref_db.abs().max()))
