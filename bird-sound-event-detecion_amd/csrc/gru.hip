@@ -319,7 +319,8 @@ __global__ __launch_bounds__(GM_THREADS) void gru_fwd_mfma_kernel(
 
 __global__ __launch_bounds__(GM_THREADS) void gru_bwd_mfma_kernel(
     const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ gates,
-    const float* __restrict__ w_hh, float* __restrict__ dxp, float* __restrict__ dgh, int B, int T) {
+    const float* __restrict__ w_hh, float* __restrict__ dxp, float* __restrict__ dgh,
+    float* __restrict__ part_bih, float* __restrict__ part_bhh, int B, int T) {
   __shared__ __align__(16) unsigned short ds[2][16][GM_DROW];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
   const int dir = blockIdx.y;
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(GM_THREADS) void gru_bwd_mfma_kernel(
   const bool rok = b0 + lq < B;
   const size_t rbase = (size_t)min(b0 + lq, B - 1) * T;
   float dhrec = 0.f;
+  float sum_r = 0.f, sum_z = 0.f, sum_n = 0.f, sum_g = 0.f;  // bias gradients: sums over time of this (row, unit)
   float q_do[2], q_r[2], q_z[2], q_n[2], q_ghn[2], q_hp[2];
   auto load_step = [&](int slot, int sc) {  // sc clamped to [0, T-1]; branch-free
     const int t = dir == 0 ? sc : T - 1 - sc;
@@ -377,6 +379,9 @@ __global__ __launch_bounds__(GM_THREADS) void gru_bwd_mfma_kernel(
       dlo[GRU_H + u] = g_f2bf(dz_pre - g_bf2f(h1));
       dlo[2 * GRU_H + u] = g_f2bf(dghn - g_bf2f(h2));
       const bool ok = live && rok;
+      const float okf = ok ? 1.0f : 0.0f;
+      sum_r = fmaf(okf, dr_pre, sum_r); sum_z = fmaf(okf, dz_pre, sum_z);
+      sum_n = fmaf(okf, dn_pre, sum_n); sum_g = fmaf(okf, dghn, sum_g);
       const size_t o = (rbase + t) * 768 + dir * GRU_G + u;
       float* px = ok ? dxp + o : gru_sink + tid;
       float* ph = ok ? dgh + o : gru_sink + tid;
@@ -395,6 +400,13 @@ __global__ __launch_bounds__(GM_THREADS) void gru_bwd_mfma_kernel(
       // the other half-iteration writes ds[j ^ 1]; ds[j] is rewritten two steps later, after a barrier every wave
       // reaches only once its reads above are done: one barrier per step
     }
+  }
+  if (part_bih) {  // per batch-row partials of db_ih = [dr, dz, dn] and db_hh = [dr, dz, d(W_hn h + b_hn)]
+    const size_t row = (size_t)blockIdx.x * GM_RB + lq;
+    float* pi = part_bih + row * 768 + dir * GRU_G + u;
+    float* ph = part_bhh + row * 768 + dir * GRU_G + u;
+    pi[0] = sum_r; pi[GRU_H] = sum_z; pi[2 * GRU_H] = sum_n;
+    ph[0] = sum_r; ph[GRU_H] = sum_z; ph[2 * GRU_H] = sum_g;
   }
 }
 
@@ -439,13 +451,16 @@ extern "C" int bsed_gru_fwd3(const float* xp, const float* w_hh, const float* b_
   return BSED_OK;
 }
 
+extern "C" int bsed_gru_bwd3_rows(int B) { return ceil_div(B, GM_RB) * GM_RB; }
+
 extern "C" int bsed_gru_bwd3(const float* dout, const float* out, const float* gates, const float* w_hh, float* dxp,
-                             float* dgh, int B, int T, void* stream) {
+                             float* dgh, float* part_bih, float* part_bhh, int B, int T, void* stream) {
   BSED_CHECK_ARG(dout && out && gates && w_hh && dxp && dgh, "bsed_gru_bwd3: null tensor");
+  BSED_CHECK_ARG((part_bih == nullptr) == (part_bhh == nullptr), "bsed_gru_bwd3: part_bih and part_bhh come together");
   BSED_CHECK_ARG(B > 0 && T > 0, "bsed_gru_bwd3: bad shape");
   dim3 grid(ceil_div(B, GM_RB), 2);
   hipLaunchKernelGGL(gru_bwd_mfma_kernel, grid, dim3(GM_THREADS), 0, (hipStream_t)stream, dout, out, gates, w_hh, dxp,
-                     dgh, B, T);
+                     dgh, part_bih, part_bhh, B, T);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }

@@ -619,6 +619,42 @@ __global__ void reduce_partials_kernel(const float* __restrict__ part, int G, in
   }
 }
 
+// Small outputs (a 16x16 or 32x32 dW reduced over ~1000 slabs) starve the kernel above of parallelism: one thread
+// per output element walks all G slabs.  Here a workgroup owns 64 consecutive elements and its S waves split the
+// slabs (wave w takes g = w, w+S, ...); the S partial sums are combined through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void reduce_partials_split_kernel(
+    const float* __restrict__ part, int G, int ntaps, int KP, int NP, int K, int N, float* __restrict__ dst,
+    long s_tap, long s_k, long s_n, int accumulate) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, S = blockDim.x >> 6;
+  const long total = (long)ntaps * KP * NP;
+  const long e = (long)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < total) {
+    int g = w;
+    for (; g + 3 * S < G; g += 4 * S) {
+      s0 += part[(size_t)g * total + e];
+      s1 += part[(size_t)(g + S) * total + e];
+      s2 += part[(size_t)(g + 2 * S) * total + e];
+      s3 += part[(size_t)(g + 3 * S) * total + e];
+    }
+    for (; g < G; g += S) s0 += part[(size_t)g * total + e];
+  }
+  red[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && e < total) {
+    float s = red[0][lane];
+    for (int i = 1; i < S; ++i) s += red[i][lane];
+    const int n = (int)(e % NP);
+    const long r = e / NP;
+    const int k = (int)(r % KP), tap = (int)(r / KP);
+    if (n < N && k < K) {
+      float* d = dst + tap * s_tap + k * s_k + n * s_n;
+      *d = accumulate ? *d + s : s;
+    }
+  }
+}
+
 // wpk[tap][k][n] = src[tap*s_tap + k*s_k + n*s_n], zero for n >= N
 __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int ntaps, int K, int N,
                                    int NP, long s_tap, long s_k, long s_n) {
@@ -923,6 +959,15 @@ extern "C" int bsed_reduce_partials(const float* part, int G, int ntaps, int KP,
                                     long s_tap, long s_k, long s_n, int accumulate, void* stream) {
   BSED_CHECK_ARG(part && dst && G > 0 && ntaps > 0 && KP >= K && NP >= N && K > 0 && N > 0, "bsed_reduce_partials: bad argument");
   const long total = (long)ntaps * KP * NP;
+  const long wgs = ceil_div(total, 64);
+  if (wgs < 1024 && G >= 8) {  // too few elements to fill the chip: split the slabs over the waves of a workgroup
+    int S = 1;
+    while (S < 16 && wgs * S < 1024 && 4 * S <= G) S *= 2;
+    hipLaunchKernelGGL(reduce_partials_split_kernel, dim3((unsigned)wgs), dim3(64 * S), 0, (hipStream_t)stream, part,
+                       G, ntaps, KP, NP, K, N, dst, s_tap, s_k, s_n, accumulate);
+    BSED_LAUNCH_CHECK();
+    return BSED_OK;
+  }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)std::min<long>(ceil_div(total, 256), 4096)), dim3(256), 0,
                      (hipStream_t)stream, part, G, ntaps, KP, NP, K, N, dst, s_tap, s_k, s_n, accumulate);
   BSED_LAUNCH_CHECK();

@@ -305,9 +305,13 @@ class CRNN(_FlatModule):
             nin, w_ih, w_hh, b_ih, b_hh = self._rnn_views(l)
             g_wih, g_whh, g_bih, g_bhh = self._rnn_grads(l)
             lay = ctx["layers"][l]
-            dxp, dgh = ops.gru_bwd(d, lay["out"], lay["gates"], w_hh, B, T, mode=self.conv_mode)
-            ops.colsum(dxp, B * T, 768, 768, g_bih)
-            ops.colsum(dgh, B * T, 768, 768, g_bhh)
+            dxp, dgh, pih, phh = ops.gru_bwd(d, lay["out"], lay["gates"], w_hh, B, T, mode=self.conv_mode)
+            if pih is not None:  # the recurrence kernel already summed the bias gradients over time per batch row
+                ops.colsum(pih, pih.shape[0], 768, 768, g_bih)
+                ops.colsum(phh, phh.shape[0], 768, 768, g_bhh)
+            else:
+                ops.colsum(dxp, B * T, 768, 768, g_bih)
+                ops.colsum(dgh, B * T, 768, 768, g_bhh)
             part, G, KP, NP = ops.wgrad(lay["inp"], dxp, 1, B * T, 1, nin, 768)
             ops.reduce_partials(part, G, 1, KP, NP, nin, 768, g_wih, 0, 1, nin)
             for dr in range(2):

@@ -362,12 +362,16 @@ def gru_bwd(dout, out, gates, w_hh, B, T, mode="fp32"):
     dxp = torch.empty((B, T, 768), device=dout.device, dtype=torch.float32)
     dgh = torch.empty((B, T, 768), device=dout.device, dtype=torch.float32)
     if mode == "bf16x3":
-        L.call("bsed_gru_bwd3", L.ptr(dout), L.ptr(out), L.ptr(gates), _fp(_dp(w_hh)), L.ptr(dxp), L.ptr(dgh), _i(B),
-               _i(T), L.stream())
+        rows = L.lib().bsed_gru_bwd3_rows(B)
+        pih = torch.empty((rows, 768), device=dout.device, dtype=torch.float32)
+        phh = torch.empty((rows, 768), device=dout.device, dtype=torch.float32)
+        L.call("bsed_gru_bwd3", L.ptr(dout), L.ptr(out), L.ptr(gates), _fp(_dp(w_hh)), L.ptr(dxp), L.ptr(dgh),
+               L.ptr(pih), L.ptr(phh), _i(B), _i(T), L.stream())
+        return dxp, dgh, pih, phh
     else:
         L.call("bsed_gru_bwd", L.ptr(dout), L.ptr(out), L.ptr(gates), _fp(_dp(w_hh)), L.ptr(dxp), L.ptr(dgh), _i(B),
                _i(T), _i(gru_rows(B)), L.stream())
-    return dxp, dgh
+    return dxp, dgh, None, None
 
 
 def head_fwd(x, w, b, B, T, K, C, attention):

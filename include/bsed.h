@@ -243,8 +243,11 @@ int bsed_gru_bwd(const float* dout, const float* out, const float* gates, const 
  * per workgroup; the default in the bf16x3 contraction mode).  Same tensors, same layouts, same reference lines. */
 int bsed_gru_fwd3(const float* xp, const float* w_hh, const float* b_hh, float* out, float* gates, int B, int T,
                   void* stream);
+/* part_bih / part_bhh (nullable, together): (bsed_gru_bwd3_rows(B), 768) per-batch-row partial sums over time of
+ * dxp / dgh, i.e. the bias gradients before the final column sum (bsed_colsum over those few rows). */
 int bsed_gru_bwd3(const float* dout, const float* out, const float* gates, const float* w_hh, float* dxp,
-                  float* dgh, int B, int T, void* stream);
+                  float* dgh, float* part_bih, float* part_bhh, int B, int T, void* stream);
+int bsed_gru_bwd3_rows(int B);
 
 /* ------------------------------------------------------------------------------------------------
  * Predictor head + losses (csrc/head.hip); replaces Predictor.forward (src/models/CRNN_GRL.py:441-460)

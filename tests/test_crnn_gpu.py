@@ -403,7 +403,7 @@ def test_gru_two_rows_per_workgroup_with_odd_batch():
     xp, _ = ops.igemm(x.detach().cuda(), wpk, 768, 1, B * T, 1, 128, bias=b_ih)
     out, gates = ops.gru_fwd(xp.view(B, T, 768), w_hh, b_hh, B, T, save_gates=True)
     np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), atol=2e-6)
-    dxp, dgh = ops.gru_bwd(dout.cuda(), out, gates, w_hh, B, T)
+    dxp, dgh, _, _ = ops.gru_bwd(dout.cuda(), out, gates, w_hh, B, T)
     wd = ops.pack_weight(w_ih, 1, 768, 128, 0, 128, 1)
     dx, _ = ops.igemm(dxp, wd, 128, 1, B * T, 1, 768)
     np.testing.assert_allclose(dx.view(B, T, 128).cpu().numpy(), x.grad.numpy(), atol=2e-5)
@@ -434,11 +434,14 @@ def test_gru_matrix_core_recurrence_vs_torch(B, T):
     assert float((out.cpu() - ref.detach()).abs().max()) < 2e-5
     out_nosave, _ = ops.gru_fwd(xp.view(B, T, 768), w_hh, b_hh, B, T, save_gates=False, mode="bf16x3")
     assert torch.equal(out_nosave, out)
-    dxp, dgh = ops.gru_bwd(dout.cuda(), out, gates, w_hh, B, T, mode="bf16x3")
+    dxp, dgh, pih, phh = ops.gru_bwd(dout.cuda(), out, gates, w_hh, B, T, mode="bf16x3")
     wd = ops.pack_weight(w_ih, 1, 768, 128, 0, 128, 1)
     dx, _ = ops.igemm(dxp, wd, 128, 1, B * T, 1, 768)
     assert float((dx.view(B, T, 128).cpu() - x.grad).abs().max()) < 1e-4
-    db = torch.zeros(768, device="cuda")
-    ops.colsum(dgh, B * T, 768, 768, db)
-    ref_db = torch.cat([gru.bias_hh_l0.grad, gru.bias_hh_l0_reverse.grad])
-    assert float((db.cpu() - ref_db).abs().max()) < 2e-4 * max(1.0, float(ref_db.abs().max()))
+    # bias gradients: the kernel's per-row sums over time, then a column sum over the (padded) batch rows
+    for part, full, ref_db in ((phh, dgh, torch.cat([gru.bias_hh_l0.grad, gru.bias_hh_l0_reverse.grad])),
+                               (pih, dxp, torch.cat([gru.bias_ih_l0.grad, gru.bias_ih_l0_reverse.grad]))):
+        db = torch.zeros(768, device="cuda")
+        ops.colsum(part, part.shape[0], 768, 768, db)
+        assert float((db.cpu() - ref_db).abs().max()) < 2e-4 * max(1.0, float(ref_db.abs().max()))
+        assert float((db - full.sum((0, 1))).abs().max()) < 1e-3

@@ -125,7 +125,7 @@ def test_gru_forward_backward_vs_torch():
     xp, _ = ops.igemm(xg, wpk, 768, 1, B * T, 1, 128, bias=b_ih)
     out, gates = ops.gru_fwd(xp.view(B, T, 768), w_hh, b_hh, B, T, save_gates=True)
     np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), atol=2e-6)
-    dxp, dgh = ops.gru_bwd(dout.cuda(), out, gates, w_hh, B, T)
+    dxp, dgh, _, _ = ops.gru_bwd(dout.cuda(), out, gates, w_hh, B, T)
     wd = ops.pack_weight(w_ih, 1, 768, 128, 0, 128, 1)
     dx, _ = ops.igemm(dxp, wd, 128, 1, B * T, 1, 768)
     np.testing.assert_allclose(dx.view(B, T, 128).cpu().numpy(), x.grad.numpy(), atol=2e-5)
