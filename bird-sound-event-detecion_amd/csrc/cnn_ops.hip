@@ -80,10 +80,15 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
   }
 }
 
-// dW0[co][tap] partials: part[blk][tap][co]
-template <int CO>
+// dW0[co][tap] partials: part[blk][tap][co].
+// BNB: dy is the gradient w.r.t. the BatchNorm OUTPUT and the BatchNorm backward d_y = A g + B (y - mean) + C
+// (coef = [A | B | C] from bn_bwd_finalize) is applied on load, so the first block's d_y (the largest tensor of the
+// network) is never written to or re-read from HBM.
+template <int CO, bool BNB>
 __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                          float* __restrict__ part, int NB, int H, int W) {
+                                                          const float* __restrict__ y, const float* __restrict__ coef,
+                                                          const float* __restrict__ mean, float* __restrict__ part,
+                                                          int NB, int H, int W) {
   __shared__ float sv[256 * (CO + 1)];
   const int tid = threadIdx.x;
   const long per_img = (long)H * W, total = per_img * NB;
@@ -102,6 +107,17 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
     for (int c = 0; c < CO; c += 4) {
       const float4 v = src[c / 4];
       g[c] = v.x; g[c + 1] = v.y; g[c + 2] = v.z; g[c + 3] = v.w;
+    }
+    if (BNB) {
+      const float4* ys = reinterpret_cast<const float4*>(y + (size_t)p * CO);
+#pragma unroll
+      for (int c = 0; c < CO; c += 4) {
+        const float4 v = ys[c / 4];
+        const float yv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          g[c + i] = fmaf(coef[c + i], g[c + i], fmaf(coef[CO + c + i], yv[i] - mean[c + i], coef[2 * CO + c + i]));
+      }
     }
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
@@ -304,12 +320,17 @@ extern "C" int bsed_conv0_fwd(const float* x, const float* w, const float* bias,
 
 extern "C" int bsed_conv0_num_tiles(int NB, int H, int W) { return NB * ceil_div((long)H * W, 256); }
 
-extern "C" int bsed_conv0_wgrad(const float* x, const float* dy, float* part, int G, int NB, int H, int W, int CO,
+extern "C" int bsed_conv0_wgrad(const float* x, const float* dy, const float* y, const float* coef, const float* mean,
+                                float* part, int G, int NB, int H, int W, int CO,
                                 void* stream) {
   BSED_CHECK_ARG(x && dy && part && G > 0 && NB > 0 && H > 0 && W > 0, "bsed_conv0_wgrad: bad argument");
   hipStream_t s = (hipStream_t)stream;
-  if (CO == 16) hipLaunchKernelGGL(conv0_wgrad_kernel<16>, dim3(G), dim3(256), 0, s, x, dy, part, NB, H, W);
-  else if (CO == 32) hipLaunchKernelGGL(conv0_wgrad_kernel<32>, dim3(G), dim3(256), 0, s, x, dy, part, NB, H, W);
+  BSED_CHECK_ARG((y == nullptr) == (coef == nullptr) && (y == nullptr) == (mean == nullptr),
+                 "bsed_conv0_wgrad: y, coef and mean come together (BatchNorm backward applied on load) or not at all");
+  if (CO == 16 && y) hipLaunchKernelGGL((conv0_wgrad_kernel<16, true>), dim3(G), dim3(256), 0, s, x, dy, y, coef, mean, part, NB, H, W);
+  else if (CO == 16) hipLaunchKernelGGL((conv0_wgrad_kernel<16, false>), dim3(G), dim3(256), 0, s, x, dy, y, coef, mean, part, NB, H, W);
+  else if (CO == 32 && y) hipLaunchKernelGGL((conv0_wgrad_kernel<32, true>), dim3(G), dim3(256), 0, s, x, dy, y, coef, mean, part, NB, H, W);
+  else if (CO == 32) hipLaunchKernelGGL((conv0_wgrad_kernel<32, false>), dim3(G), dim3(256), 0, s, x, dy, y, coef, mean, part, NB, H, W);
   else { bsed_set_error("bsed_conv0_wgrad: first-layer width %d not built (16 or 32)", CO); return BSED_ERR_ARG; }
   BSED_LAUNCH_CHECK();
   return BSED_OK;
@@ -360,8 +381,8 @@ extern "C" int bsed_bn_eval(int C, float eps, const float* gamma, const float* b
 extern "C" int bsed_bn_bwd(const float* partial, long ntiles, int C, double count, const float* gamma,
                            const float* mean, const float* invstd, float* dgamma, float* dbeta, int accumulate,
                            float* g_inout, const float* y, long n_elems, float* coef, void* scratch, void* stream) {
-  BSED_CHECK_ARG(partial && gamma && mean && invstd && dgamma && dbeta && g_inout && y && coef && scratch,
-                 "bsed_bn_bwd: null tensor");
+  BSED_CHECK_ARG(partial && gamma && mean && invstd && dgamma && dbeta && coef && scratch, "bsed_bn_bwd: null tensor");
+  BSED_CHECK_ARG((g_inout == nullptr) == (y == nullptr), "bsed_bn_bwd: g_inout and y come together");
   BSED_CHECK_ARG(ntiles > 0 && C > 0 && C % 4 == 0 && n_elems % C == 0, "bsed_bn_bwd: bad shape");
   hipStream_t s = (hipStream_t)stream;
   double* sc = (double*)scratch;
@@ -369,6 +390,10 @@ extern "C" int bsed_bn_bwd(const float* partial, long ntiles, int C, double coun
   if (rc) return rc;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s,
                      sc + (size_t)STATS_CHUNKS * 2 * C, C, count, gamma, mean, invstd, dgamma, dbeta, accumulate, coef);
+  if (!g_inout) {  // coefficients only: the consumer applies the affine map on load (bsed_conv0_wgrad)
+    BSED_LAUNCH_CHECK();
+    return BSED_OK;
+  }
   const long n4 = n_elems / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)std::min<long>(ceil_div(n4, 256), 8192)), dim3(256), 0, s,
                      g_inout, y, coef, mean, n4, C);

@@ -365,25 +365,29 @@ class CRNN(_FlatModule):
                 # (3) g = d_lin @ W_glu + gate term  (gradient w.r.t. the BatchNorm output), with BN-backward sums
                 wgT = ops.pack_weight(glu.weight, 1, co, co, 0, co, 1)
                 g, st2 = ops.igemm(dlin, wgT, co, B, Hh, Ww, co, epilogue=ops.EPI_ADD_STATS2, out=tt, out2=tt, e_src=y)
+            cw = self.P(f"cnn.conv{i}.weight")
+            # conv bias feeds a train-mode BatchNorm: its gradient is exactly zero (DESIGN.md), leave it
+            if i == 0:
+                # (4') the first block's d_y is only consumed by conv0's weight gradient: BatchNorm backward is applied
+                # on load there, the largest tensor of the network is neither rewritten nor re-read
+                coef = ops.bn_bwd(st2, co, float(B * Hh * Ww), bn.weight, blk["mean"], blk["invstd"], bn.weight.grad,
+                                  bn.bias.grad, g, y, apply=False)
+                part, G = ops.conv0_wgrad(blk["inp"], g, B, Hh, Ww, co, y=y, coef=coef, mean=blk["mean"])
+                ops.reduce_partials(part, G, 9, 1, co, 1, co, cw.grad, 1, 9, 9)
+                continue
             # (4) BatchNorm backward -> d_y in place
             ops.bn_bwd(st2, co, float(B * Hh * Ww), bn.weight, blk["mean"], blk["invstd"], bn.weight.grad,
                        bn.bias.grad, g, y)
             dy = g
-            cw = self.P(f"cnn.conv{i}.weight")
-            # conv bias feeds a train-mode BatchNorm: its gradient is exactly zero (DESIGN.md), leave it
-            if i == 0:
-                part, G = ops.conv0_wgrad(blk["inp"], dy, B, Hh, Ww, co)
-                ops.reduce_partials(part, G, 9, 1, co, 1, co, cw.grad, 1, 9, 9)
+            part, G, KP, NP = ops.wgrad(blk["inp"], dy, B, Hh, Ww, cin, co, taps=ops.TAPS3x3)
+            ops.reduce_partials(part, G, 9, KP, NP, cin, co, cw.grad, 1, 9, cin * 9)
+            flipped = [(-a, -b) for a, b in ops.TAPS3x3]
+            if self.conv_mode == "bf16x3":
+                wd3 = ops.pack_weight3(cw, 9, co, cin, 1, cin * 9, 9)
+                dpool, _ = ops.igemm3(dy, wd3, cin, B, Hh, Ww, co, flipped)
             else:
-                part, G, KP, NP = ops.wgrad(blk["inp"], dy, B, Hh, Ww, cin, co, taps=ops.TAPS3x3)
-                ops.reduce_partials(part, G, 9, KP, NP, cin, co, cw.grad, 1, 9, cin * 9)
-                flipped = [(-a, -b) for a, b in ops.TAPS3x3]
-                if self.conv_mode == "bf16x3":
-                    wd3 = ops.pack_weight3(cw, 9, co, cin, 1, cin * 9, 9)
-                    dpool, _ = ops.igemm3(dy, wd3, cin, B, Hh, Ww, co, flipped)
-                else:
-                    wd = ops.pack_weight(cw, 9, co, cin, 1, cin * 9, 9)
-                    dpool, _ = ops.igemm(dy, wd, cin, B, Hh, Ww, co, taps=flipped)
+                wd = ops.pack_weight(cw, 9, co, cin, 1, cin * 9, 9)
+                dpool, _ = ops.igemm(dy, wd, cin, B, Hh, Ww, co, taps=flipped)
 
     def forward(self, x):
         if torch.is_grad_enabled() and self.training:

@@ -244,10 +244,12 @@ def conv0_fwd(x, w, bias, NB, H, W, CO, want_stats):
     return y, stats
 
 
-def conv0_wgrad(x, dy, NB, H, W, CO):
+def conv0_wgrad(x, dy, NB, H, W, CO, y=None, coef=None, mean=None):
+    """y/coef/mean given: dy is dL/d(BatchNorm output) and BatchNorm's backward is applied on load"""
     G = min(1024, max(1, (NB * H * W) // 256))
     part = torch.empty((G, 9, CO), device=x.device, dtype=torch.float32)
-    L.call("bsed_conv0_wgrad", L.ptr(x), L.ptr(dy), L.ptr(part), _i(G), _i(NB), _i(H), _i(W), _i(CO), L.stream())
+    L.call("bsed_conv0_wgrad", L.ptr(x), L.ptr(dy), _fp(_p(y)), _fp(_p(coef)), _fp(_p(mean)), L.ptr(part), _i(G),
+           _i(NB), _i(H), _i(W), _i(CO), L.stream())
     return part, G
 
 
@@ -314,12 +316,16 @@ def bn_eval(C, eps, gamma, beta, rmean, rvar):
     return scale, shift
 
 
-def bn_bwd(stats, C, count, gamma, mean, invstd, dgamma, dbeta, g_inout, y):
+def bn_bwd(stats, C, count, gamma, mean, invstd, dgamma, dbeta, g_inout, y, apply=True):
+    """apply=False: only dgamma/dbeta and the (3,C) coefficients [A|B|C] of d_y = A g + B (y-mean) + C (returned);
+    the consumer applies the map on load (conv0_wgrad)."""
     dev = y.device
     coef = torch.empty((3, C), device=dev, dtype=torch.float32)
     L.call("bsed_bn_bwd", L.ptr(stats), ctypes.c_long(stats.shape[0]), _i(C), ctypes.c_double(count), _fp(_dp(gamma)),
-           L.ptr(mean), L.ptr(invstd), _fp(_dp(dgamma)), _fp(_dp(dbeta)), _i(1), L.ptr(g_inout), L.ptr(y),
+           L.ptr(mean), L.ptr(invstd), _fp(_dp(dgamma)), _fp(_dp(dbeta)), _i(1),
+           L.ptr(g_inout) if apply else None, L.ptr(y) if apply else None,
            ctypes.c_long(y.numel()), L.ptr(coef), L.ptr(stats_scratch(C, dev), torch.float64), L.stream())
+    return coef
 
 
 def stats_to_grad(stats, C, which, dst):

@@ -155,9 +155,11 @@ int bsed_pack_weight(const float* src, float* dst, int ntaps, int K, int N, int 
 int bsed_conv0_fwd(const float* x, const float* w, const float* bias, float* y, float* stats, int NB, int H,
                    int W, int CO, void* stream);
 int bsed_conv0_num_tiles(int NB, int H, int W);
-/* dW of the first conv: part (G, 9, CO) partial slabs for bsed_reduce_partials */
-int bsed_conv0_wgrad(const float* x, const float* dy, float* part, int G, int NB, int H, int W, int CO,
-                     void* stream);
+/* dW of the first conv: part (G, 9, CO) partial slabs for bsed_reduce_partials.  With y / coef / mean (together or
+ * all NULL) dy is the gradient w.r.t. the BatchNorm OUTPUT and BatchNorm's backward (coef from bsed_bn_bwd in
+ * coefficients-only mode) is applied on load: the first block's d_y never touches HBM. */
+int bsed_conv0_wgrad(const float* x, const float* dy, const float* y, const float* coef, const float* mean,
+                     float* part, int G, int NB, int H, int W, int CO, void* stream);
 /* fp64 scratch needed by the statistics reductions below */
 size_t bsed_stats_scratch_bytes(int C);
 /* BatchNorm2d(eps, momentum) in train mode (src/models/CNN.py:49): per-tile partials -> batch mean /
@@ -171,7 +173,8 @@ int bsed_bn_finalize(const float* partial, long ntiles, int C, double count, flo
 int bsed_bn_eval(int C, float eps, const float* gamma, const float* beta, const float* running_mean,
                  const float* running_var, float* scale, float* shift, void* stream);
 /* BatchNorm backward: partial = per-tile (sum g, sum g*y); writes dgamma/dbeta and turns g (n_elems,
- * NHWC, in place) into d_y = A g + B (y - mean) + C;  coef is a (3,C) work buffer */
+ * NHWC, in place) into d_y = A g + B (y - mean) + C;  coef (3,C) receives [A | B | C].  g_inout = y = NULL:
+ * coefficients only (the consumer applies the map on load). */
 int bsed_bn_bwd(const float* partial, long ntiles, int C, double count, const float* gamma, const float* mean,
                 const float* invstd, float* dgamma, float* dbeta, int accumulate, float* g_inout, const float* y,
                 long n_elems, float* coef, void* scratch, void* stream);
