@@ -1,0 +1,416 @@
+// GLU stage (BatchNorm-apply -> Linear -> sigmoid gate -> Dropout -> AvgPool) in the split-fp32 ("bf16x3") contraction
+// mode: forward and fused backward on v_mfma_f32_32x32x16_bf16, activations never staged through LDS.
+//
+// Reference math (src/models/CNN.py:5-16,59-67 and its autograd):
+//   xn = y*scale + shift,  lin = xn W^T + b,  sig = sigmoid(xn),  res = lin*sig,  pooled = avgpool(dropout(res))
+//   d_res = unpool(d_pooled) * mask/(1-p) / window
+//   d_lin = d_res*sig                         -> db += sum d_lin,  dW += d_lin^T xn
+//   g     = d_lin W + d_res*lin*sig*(1-sig)   = dL/d xn, plus the BatchNorm-backward sums (sum g, sum g*y)
+//
+// The fp32-core kernels (igemm.hip EPI_GLU_POOL, glu_bwd.hip) stage the activation tile in LDS and run at 25-70 TFLOP/s
+// where the stage is HBM-bound by a wide margin on the bf16 cores.  Here every operand is fetched in the register
+// layout its MFMA wants (lane maps: A[row = lane&31][k = 8*(lane>>5)+j], B[k = 8*(lane>>5)+j][col = lane&31],
+// C[row = (r&3)+8*(r>>2)+4*(lane>>5)][col = lane&31]):
+//   GEMM1 (lin = xn W^T): A fragments straight from global y (lane = position, 8 consecutive channels = 32 B),
+//          BatchNorm applied and split into bf16 hi/lo in registers; B fragments (W^T, hi and lo) pre-split once per
+//          workgroup into LDS in fragment order (16 B per lane, conflict-free).
+//   epilogue 1: y is re-read (L1/L2-hot) in the C layout (lane = channel, 16 positions), d_lin and the gate term are
+//          formed there; the gate term stays in the accumulators and seeds GEMM2.
+//   GEMM2 (g = d_lin W + gate term): d_lin crosses from the C layout (lane = channel) to the A layout (lane =
+//          position) through a wave-private bf16 hi|lo LDS tile -- the only activation-sized LDS traffic of the kernel.
+//   GEMM3 (dW += d_lin^T xn, K = positions): the C layout IS the K-major operand layout: a lane holds 16 positions of
+//          one channel, and both operands use the same position order, so d_lin (A) and xn (B) fragments are packed
+//          from the registers that epilogue 1 already holds.  Each wave accumulates dW over its own 32 positions of
+//          every tile (persistent accumulators) and writes one partial slab at the end (deterministic reduction by
+//          bsed_reduce_partials; no float atomics).
+// fp32 accumulation everywhere; the dropped lo*lo term is 2^-16 relative.
+#include "bsed_common.h"
+#include "../../include/bsed.h"
+#include <algorithm>
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define G3_THREADS 256
+#define G3_M 128
+
+struct Glu3Params {
+  const float* y; const float* scale; const float* shift;
+  const float* w;      // (C,C) Linear weight, [n][c]
+  const float* bias; const float* dpool;
+  float* g; float* part_dw; float* part_db; float* part_st;
+  float* pooled;       // forward output
+  int NB, H, W, TH, TW, lgTW, tilesH, tilesW, ntiles;
+  int ph, pw, Hp, Wp;
+  float drop_p; uint32_t rng_stream; uint64_t seed;
+};
+
+// Orders this wave's LDS writes before its later LDS reads.  The hardware executes one wave's LDS instructions in
+// issue order, but the COMPILER may move a 16-byte fragment load above the 2-byte element stores that produce it (type
+// based alias analysis sees unrelated types; __builtin_amdgcn_wave_barrier() does not order memory operations).
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ int crow3g(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+__device__ __forceinline__ uint32_t rne_bits(float x) {  // bf16 round-to-nearest-even, result in the UPPER 16 bits
+  const uint32_t u = __float_as_uint(x);
+  return u + 0x7FFFu + ((u >> 16) & 1u);
+}
+// two fp32 values -> one packed word of bf16 hi parts and one of bf16 lo parts (element 0 in the low half)
+__device__ __forceinline__ void split_pack2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const uint32_t ua = rne_bits(a) & 0xFFFF0000u, ub = rne_bits(b) & 0xFFFF0000u;
+  const float la = a - __uint_as_float(ua), lb = b - __uint_as_float(ub);
+  hi = ub | (ua >> 16);
+  lo = (rne_bits(lb) & 0xFFFF0000u) | (rne_bits(la) >> 16);
+}
+__device__ __forceinline__ void split_pack8(const float* v, bf16x8& hi, bf16x8& lo) {
+  u32x4 h, l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t hh, ll;
+    split_pack2(v[2 * i], v[2 * i + 1], hh, ll);
+    h[i] = hh; l[i] = ll;
+  }
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
+
+// LDS fragment tables of the two weight operands: frag (j, ks, hi|lo) at ((j*KS + ks)*2 + hl)*64 + lane, 16 B each
+//   WF (GEMM1 B = W^T): lane (n = 32j + li, lh) holds W[n][16ks + 8lh .. +8]
+//   WB (GEMM2 B = W)  : lane (c = 32j + li, lh) holds W[16ks + 8lh .. +8][c]
+template <int C>
+__device__ __forceinline__ void build_weight_frags(const float* __restrict__ w, bf16x8* WF, bf16x8* WB, int tid) {
+  constexpr int NT = C / 32, KS = C / 16;
+  for (int f = tid; f < NT * KS * 64; f += G3_THREADS) {
+    const int lane = f & 63, li = lane & 31, lh = lane >> 5;
+    const int ks = (f >> 6) % KS, j = (f >> 6) / KS;
+    float v[8];
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = w[(size_t)(32 * j + li) * C + 16 * ks + 8 * lh + q];
+    split_pack8(v, hi, lo);
+    WF[((j * KS + ks) * 2 + 0) * 64 + lane] = hi;
+    WF[((j * KS + ks) * 2 + 1) * 64 + lane] = lo;
+    if (WB) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = w[(size_t)(16 * ks + 8 * lh + q) * C + 32 * j + li];
+      split_pack8(v, hi, lo);
+      WB[((j * KS + ks) * 2 + 0) * 64 + lane] = hi;
+      WB[((j * KS + ks) * 2 + 1) * 64 + lane] = lo;
+    }
+  }
+}
+
+// GEMM1 A fragments of this wave's 32 positions: BatchNorm-applied, split
+template <int C>
+__device__ __forceinline__ void load_a_frags(const Glu3Params& P, const float* s_sc, const float* s_sh, int nb, int th0,
+                                             int tw0, int wave, int li, int lh, bf16x8* a_hi, bf16x8* a_lo) {
+  constexpr int KS = C / 16;
+  const int mA = wave * 32 + li;
+  const int gh = th0 + (mA >> P.lgTW), gw = tw0 + (mA & (P.TW - 1));
+  const bool ok = gh < P.H;
+  const float* rp = P.y + (((size_t)nb * P.H + (ok ? gh : 0)) * P.W + gw) * C + 8 * lh;
+  float4 raw[KS][2];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    raw[ks][0] = *reinterpret_cast<const float4*>(rp + 16 * ks);
+    raw[ks][1] = *reinterpret_cast<const float4*>(rp + 16 * ks + 4);
+  }
+  const float okf = ok ? 1.0f : 0.0f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const float4 s0 = *reinterpret_cast<const float4*>(s_sc + 16 * ks + 8 * lh);
+    const float4 s1 = *reinterpret_cast<const float4*>(s_sc + 16 * ks + 8 * lh + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(s_sh + 16 * ks + 8 * lh);
+    const float4 h1 = *reinterpret_cast<const float4*>(s_sh + 16 * ks + 8 * lh + 4);
+    float v[8];
+    v[0] = fmaf(raw[ks][0].x, s0.x, h0.x) * okf; v[1] = fmaf(raw[ks][0].y, s0.y, h0.y) * okf;
+    v[2] = fmaf(raw[ks][0].z, s0.z, h0.z) * okf; v[3] = fmaf(raw[ks][0].w, s0.w, h0.w) * okf;
+    v[4] = fmaf(raw[ks][1].x, s1.x, h1.x) * okf; v[5] = fmaf(raw[ks][1].y, s1.y, h1.y) * okf;
+    v[6] = fmaf(raw[ks][1].z, s1.z, h1.z) * okf; v[7] = fmaf(raw[ks][1].w, s1.w, h1.w) * okf;
+    split_pack8(v, a_hi[ks], a_lo[ks]);
+  }
+}
+
+__device__ float g3_sink[G3_M];
+
+__device__ __forceinline__ float drop_mul32(uint32_t e, uint32_t key, uint32_t thr, float scale) {
+  // == drop_mul(e, ...) of bsed_common.h for element indices below 2^32 (checked on the host)
+  const uint32_t h = mix32(e * 0x9E3779B1u + key);
+  return (h >> 8) >= thr ? scale : 0.f;
+}
+
+template <int C>
+__global__ __launch_bounds__(G3_THREADS, C == 32 ? 3 : 2) void glu_bwd3_kernel(const Glu3Params P) {
+  constexpr int NT = C / 32, KS = C / 16;
+  constexpr int DP = 2 * C + 8;  // ushorts per row of the d_lin tile: C hi | C lo | 8 pad ((2C+8)*2 B = odd x 16 B)
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  bf16x8* WF = reinterpret_cast<bf16x8*>(smem_raw);
+  bf16x8* WB = WF + NT * KS * 2 * 64;
+  float* s_sc = reinterpret_cast<float*>(WB + NT * KS * 2 * 64);
+  float* s_sh = s_sc + C;
+  unsigned short* Dall = reinterpret_cast<unsigned short*>(s_sh + C);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  unsigned short* D = Dall + wave * 32 * DP;  // wave-private
+
+  build_weight_frags<C>(P.w, WF, WB, tid);
+  for (int i = tid; i < C; i += G3_THREADS) { s_sc[i] = P.scale[i]; s_sh[i] = P.shift[i]; }
+  __syncthreads();
+
+  const int sph = P.ph >> 1, spw = P.pw >> 1;
+  const float inv_pool = 1.0f / (float)(P.ph * P.pw);
+  const uint32_t dkey = drop_key(P.rng_stream, P.seed), dthr = drop_threshold(P.drop_p);
+  const float dscale = P.drop_p > 0.f ? 1.0f / (1.0f - P.drop_p) : 1.0f;
+
+  float bias[NT], csc[NT], csh[NT], sdb[NT], sgs[NT], sgy[NT];
+  f32x16 acc3[NT][NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    bias[j] = P.bias[32 * j + li];
+    csc[j] = s_sc[32 * j + li]; csh[j] = s_sh[32 * j + li];
+    sdb[j] = 0.f; sgs[j] = 0.f; sgy[j] = 0.f;
+#pragma unroll
+    for (int jc = 0; jc < NT; ++jc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc3[j][jc][r] = 0.f;
+  }
+
+  for (int tile0 = blockIdx.x; tile0 < P.ntiles; tile0 += gridDim.x) {
+    int tile = tile0;
+    const int tw_i = tile % P.tilesW; tile /= P.tilesW;
+    const int th_i = tile % P.tilesH;
+    const int nb = tile / P.tilesH;
+    const int th0 = th_i * P.TH, tw0 = tw_i * P.TW;
+    // opaque copy of the lane's row offset: keeps the per-row index arithmetic of the epilogues (16 rows x several
+    // values, all tile-invariant) from being hoisted out of the tile loop into ~40 long-lived registers
+    int lhv = 4 * lh;
+    asm volatile("" : "+v"(lhv));
+
+    // ---- GEMM1: lin = xn W^T
+    f32x16 acc[NT];
+    {
+      bf16x8 a_hi[KS], a_lo[KS];
+      load_a_frags<C>(P, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const bf16x8 b_hi = WF[((j * KS + ks) * 2 + 0) * 64 + lane];
+          const bf16x8 b_lo = WF[((j * KS + ks) * 2 + 1) * 64 + lane];
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[ks], b_hi, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_lo, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_hi, acc[j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue 1 (C layout: lane = channel 32j+li, register r = position wave*32 + crow(r, lh)).
+    // d_lin and xn leave it already packed as the GEMM3 operand fragments (frag f = registers 8f..8f+7).
+    bf16x8 da_hi[NT][2], da_lo[NT][2], xb_hi[NT][2], xb_lo[NT][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      float dl8[NT][8], xn8[NT][8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int rg = 2 * f + h;
+        // branch-free: rows below the image / outside the pooled extent read a clamped address and are masked
+        float dv[4][NT], yv[4][NT], mk[4];
+        uint32_t posv[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int mm = wave * 32 + 8 * rg + lhv + rr;
+          const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (P.TW - 1));
+          const int gph = gh >> sph, gpw = gw >> spw;
+          mk[rr] = (gh < P.H && gph < P.Hp && gpw < P.Wp) ? inv_pool : 0.f;
+          posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
+          const uint32_t dpo = ((uint32_t)(nb * P.Hp + min(gph, P.Hp - 1)) * (uint32_t)P.Wp + min(gpw, P.Wp - 1)) * C + li;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            dv[rr][j] = P.dpool[dpo + 32 * j];
+            yv[rr][j] = P.y[posv[rr] + 32 * j];
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int r = 4 * rg + rr;
+          const int row = 8 * rg + lhv + rr;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int n = 32 * j + li;
+            const float xn = fmaf(yv[rr][j], csc[j], csh[j]);
+            const float sg = sigmoid_fast(xn);
+            const float lin = acc[j][r] + bias[j];
+            const float dres = dv[rr][j] * mk[rr] * drop_mul32(posv[rr] + 32 * j, dkey, dthr, dscale);
+            const float dl = dres * sg;
+            const float tt = dres * lin * sg * (1.0f - sg);
+            sdb[j] += dl;
+            dl8[j][4 * h + rr] = dl;
+            xn8[j][4 * h + rr] = xn;
+            acc[j][r] = tt;
+            const uint32_t hb = rne_bits(dl) & 0xFFFF0000u;
+            D[row * DP + n] = (unsigned short)(hb >> 16);
+            D[row * DP + C + n] = (unsigned short)(rne_bits(dl - __uint_as_float(hb)) >> 16);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        split_pack8(dl8[j], da_hi[j][f], da_lo[j][f]);
+        split_pack8(xn8[j], xb_hi[j][f], xb_lo[j][f]);
+      }
+    }
+    wave_lds_fence();  // the tile is wave-private: LDS operations of one wave execute in issue order
+
+    // ---- GEMM2: g = d_lin W + gate term (already in acc)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 d_hi = *reinterpret_cast<const bf16x8*>(D + li * DP + 16 * ks + 8 * lh);
+      const bf16x8 d_lo = *reinterpret_cast<const bf16x8*>(D + li * DP + C + 16 * ks + 8 * lh);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const bf16x8 b_hi = WB[((j * KS + ks) * 2 + 0) * 64 + lane];
+        const bf16x8 b_lo = WB[((j * KS + ks) * 2 + 1) * 64 + lane];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_lo, b_hi, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_hi, b_lo, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_hi, b_hi, acc[j], 0, 0, 0);
+      }
+    }
+    wave_lds_fence();
+
+    // ---- GEMM3: dW[n][c] += sum over this wave's 32 positions of d_lin[p][n] xn[p][c]; operands from registers
+#pragma unroll
+    for (int jc = 0; jc < NT; ++jc)
+#pragma unroll
+      for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          acc3[jn][jc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da_lo[jn][f], xb_hi[jc][f], acc3[jn][jc], 0, 0, 0);
+          acc3[jn][jc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da_hi[jn][f], xb_lo[jc][f], acc3[jn][jc], 0, 0, 0);
+          acc3[jn][jc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da_hi[jn][f], xb_hi[jc][f], acc3[jn][jc], 0, 0, 0);
+        }
+
+    // ---- epilogue 2: write g, BatchNorm-backward sums (y re-read: cache-hot)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float yv[4][NT], okf[4];
+      uint32_t posv[4];
+      float* gdst[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int mm = wave * 32 + 8 * rg + lhv + rr;
+        const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (P.TW - 1));
+        okf[rr] = gh < P.H ? 1.0f : 0.0f;
+        posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
+        gdst[rr] = gh < P.H ? P.g + posv[rr] : g3_sink + li;  // rows below the image store to a sink: no branch
+#pragma unroll
+        for (int j = 0; j < NT; ++j) yv[rr][j] = P.y[posv[rr] + 32 * j];
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float gv = acc[j][4 * rg + rr] * okf[rr];  // (rows below the image carry g = 0 anyway: d_lin = gate = 0)
+          gdst[rr][32 * j] = gv;
+          sgs[j] += gv;
+          sgy[j] = fmaf(gv, yv[rr][j], sgy[j]);
+        }
+      }
+    }
+  }
+
+  // ---- partials: one dW slab per WAVE (4 per workgroup), db / BN sums per workgroup
+#pragma unroll
+  for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+    for (int jc = 0; jc < NT; ++jc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = 32 * jn + crow3g(r, lh);
+        P.part_dw[(((size_t)blockIdx.x * 4 + wave) * C + n) * C + 32 * jc + li] = acc3[jn][jc][r];
+      }
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(Dall);  // [4 waves][3][C]
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const float a = sdb[j] + __shfl_xor(sdb[j], 32, 64);
+    const float b = sgs[j] + __shfl_xor(sgs[j], 32, 64);
+    const float c = sgy[j] + __shfl_xor(sgy[j], 32, 64);
+    if (lh == 0) {
+      red[(wave * 3 + 0) * C + 32 * j + li] = a;
+      red[(wave * 3 + 1) * C + 32 * j + li] = b;
+      red[(wave * 3 + 2) * C + 32 * j + li] = c;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 3 * C; e += G3_THREADS) {
+    const int which = e / C, n = e % C;
+    const float s = red[(0 * 3 + which) * C + n] + red[(1 * 3 + which) * C + n] + red[(2 * 3 + which) * C + n] +
+                    red[(3 * 3 + which) * C + n];
+    if (which == 0) {
+      P.part_db[((size_t)blockIdx.x * 2 + 0) * C + n] = s;
+      P.part_db[((size_t)blockIdx.x * 2 + 1) * C + n] = 0.f;
+    } else {
+      P.part_st[((size_t)blockIdx.x * 2 + (which - 1)) * C + n] = s;
+    }
+  }
+}
+
+template <int C>
+static size_t glu_bwd3_smem() {
+  constexpr int NT = C / 32, KS = C / 16;
+  return (size_t)2 * NT * KS * 2 * 64 * 16 + 2 * C * sizeof(float) + (size_t)4 * 32 * (2 * C + 8) * 2;
+}
+
+template <int C>
+static int launch_glu_bwd3(const Glu3Params& P, int G, hipStream_t s) {
+  const size_t smem = glu_bwd3_smem<C>();
+  static bool done = false;
+  if (!done) {
+    BSED_HIP(hipFuncSetAttribute((const void*)glu_bwd3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+  }
+  hipLaunchKernelGGL((glu_bwd3_kernel<C>), dim3(G), dim3(G3_THREADS), smem, s, P);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+static int fill_params(Glu3Params& P, int NB, int H, int W, int C, int TH, int TW, int ph, int pw, const char* who) {
+  BSED_CHECK_ARG(NB > 0 && H > 0 && W > 0 && TH * TW == G3_M && W % TW == 0, "%s: bad shape", who);
+  BSED_CHECK_ARG((ph == 1 || ph == 2) && (pw == 1 || pw == 2), "%s: pooling windows must be 1 or 2", who);
+  P.NB = NB; P.H = H; P.W = W; P.TH = TH; P.TW = TW;
+  P.lgTW = 0;
+  while ((1 << P.lgTW) < TW) ++P.lgTW;
+  BSED_CHECK_ARG((1 << P.lgTW) == TW, "%s: TW must be a power of two", who);
+  P.tilesH = ceil_div(H, TH); P.tilesW = W / TW;
+  const long ntiles = (long)NB * P.tilesH * P.tilesW;
+  BSED_CHECK_ARG(ntiles < (1L << 31) && (long)NB * H * W * C < (1L << 32),
+                 "%s: activation tensor beyond the 32-bit element offsets of this kernel", who);
+  P.ntiles = (int)ntiles;
+  P.ph = ph; P.pw = pw; P.Hp = H / ph; P.Wp = W / pw;
+  return BSED_OK;
+}
+
+extern "C" int bsed_glu_bwd3_slabs(int C) { (void)C; return 4; }
+
+// workgroups of one resident round (persistent kernel): LDS- and register-limited occupancy x 256 CUs
+extern "C" int bsed_glu_bwd3_auto_g(int C) { return C == 32 ? 768 : 512; }
+
+extern "C" int bsed_glu_bwd3(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
+                             const float* dpool, float* g, float* part_dw, float* part_db, float* part_st, int G,
+                             int NB, int H, int W, int C, int TH, int TW, int ph, int pw, float drop_p,
+                             uint32_t rng_stream, uint64_t seed, void* stream) {
+  BSED_CHECK_ARG(y && scale && shift && w && bias && dpool && g && part_dw && part_db && part_st,
+                 "bsed_glu_bwd3: null tensor");
+  BSED_CHECK_ARG(C == 32 || C == 64, "bsed_glu_bwd3: built for C in {32,64} (got %d)", C);
+  Glu3Params P;
+  int rc = fill_params(P, NB, H, W, C, TH, TW, ph, pw, "bsed_glu_bwd3");
+  if (rc) return rc;
+  BSED_CHECK_ARG(G > 0 && G <= P.ntiles, "bsed_glu_bwd3: G must be in 1..%d tiles", P.ntiles);
+  P.y = y; P.scale = scale; P.shift = shift; P.w = w; P.bias = bias; P.dpool = dpool;
+  P.g = g; P.part_dw = part_dw; P.part_db = part_db; P.part_st = part_st; P.pooled = nullptr;
+  P.drop_p = drop_p; P.rng_stream = rng_stream; P.seed = seed;
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 64) return launch_glu_bwd3<64>(P, G, s);
+  return launch_glu_bwd3<32>(P, G, s);
+}

@@ -20,6 +20,8 @@ import math
 from collections import OrderedDict
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -135,6 +137,7 @@ class CRNN(_FlatModule):
         self.n_hidden = n_RNN_cell
         self.seed = 0
         self.fused_glu_bwd = True  # False = the unfused 4-launch chain (kept as a cross-check in the tests)
+        self.glu3 = os.environ.get("BSED_GLU3", "1") != "0"  # split-fp32 GLU kernels (csrc/glu3.hip)
         # "bf16x3" (default): the 3x3 conv forward / data-gradient contractions and the GRU projection GEMMs run on the
         # bf16 matrix cores with split-fp32 operands (csrc/igemm3.hip; measured 5.5e-6 on the logits of the reference
         # config, 18x inside the 1e-4 bar).  "fp32": exact fp32 matrix cores everywhere (9.6e-7 on the logits).
@@ -341,6 +344,13 @@ class CRNN(_FlatModule):
                 g, pdw, pdb, st2, G = ops.glu16_bwd(y, blk["scale"], blk["shift"], glu.weight, glu.bias,
                                                     dpool.contiguous(), B, Hh, Ww, (ph, pw), drop_b, 100 + i, seed)
                 ops.reduce_partials(pdw, G, 1, 16, 16, 16, 16, glu.weight.grad, 0, 16, 1)
+                ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
+            elif co in (32, 64) and self.fused_glu_bwd and self.conv_mode == "bf16x3" and self.glu3:
+                # all three contractions on the bf16 cores, operands fetched in MFMA register layout (csrc/glu3.hip)
+                g, pdw, pdb, st2, G, slabs = ops.glu_bwd3(y, blk["scale"], blk["shift"], glu.weight, glu.bias,
+                                                          dpool.contiguous(), B, Hh, Ww, co, (ph, pw), drop_b, 100 + i,
+                                                          seed)
+                ops.reduce_partials(pdw, G * slabs, 1, co, co, co, co, glu.weight.grad, 0, co, 1)
                 ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
             elif co in (32, 64, 128) and self.fused_glu_bwd:
                 # three chained MFMA contractions per tile, y read once, g written once (csrc/glu_bwd.hip)

@@ -298,6 +298,27 @@ def glu_bwd_fused(y, scale, shift, wfwd, w, bias, dpool, B, H, W, C, pool, drop_
     return g, part_dw, part_db, part_st, G, slabs
 
 
+def glu_bwd3(y, scale, shift, w, bias, dpool, B, H, W, C, pool, drop_p, rng_stream, seed):
+    """split-fp32 fused GLU backward (C in {32,64}); returns like glu_bwd_fused"""
+    ph, pw = pool
+    dev = y.device
+    TH, TW = tile_for(W)
+    ntiles = B * ((H + TH - 1) // TH) * (W // TW)
+    G = int(min(ntiles, L.lib().bsed_glu_bwd3_auto_g(C)))
+    slabs = L.lib().bsed_glu_bwd3_slabs(C)
+    g = torch.empty_like(y)
+    part_dw = torch.empty((G * slabs, C, C), device=dev, dtype=torch.float32)
+    part_db = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
+    part_st = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
+    flops = 3 * 2.0 * B * H * W * C * C
+    _launch((f"glu_bwd3_kernel<{C}>", 1, C, C, H, W), flops,
+            lambda: L.call("bsed_glu_bwd3", L.ptr(y), L.ptr(scale), L.ptr(shift), _fp(_dp(w)), _fp(_dp(bias)),
+                           L.ptr(dpool), L.ptr(g), L.ptr(part_dw), L.ptr(part_db), L.ptr(part_st), _i(G), _i(B), _i(H),
+                           _i(W), _i(C), _i(TH), _i(TW), _i(ph), _i(pw), ctypes.c_float(drop_p),
+                           ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream()))
+    return g, part_dw, part_db, part_st, G, slabs
+
+
 def bn_finalize(stats, C, count, eps, momentum, gamma, beta, rmean, rvar, nbt):
     dev = stats.device
     mean, invstd, scale, shift = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(4))

@@ -210,6 +210,16 @@ int bsed_glu_bwd_fused(const float* y, const float* scale, const float* shift, c
                        int pw, float drop_p, uint32_t rng_stream, uint64_t seed, void* stream);
 int bsed_glu_bwd_slabs(int C);
 
+/* The same fused GLU backward in the split-fp32 ("bf16x3") contraction mode for C in {32,64} (csrc/glu3.hip): all
+ * three contractions on the bf16 matrix cores, activations never staged through LDS.  w = the (C,C) Linear weight.
+ * part_dw holds G * bsed_glu_bwd3_slabs(C) slabs; bsed_glu_bwd3_auto_g(C) = workgroups of one resident round. */
+int bsed_glu_bwd3(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
+                  const float* dpool, float* g, float* part_dw, float* part_db, float* part_st, int G, int NB, int H,
+                  int W, int C, int TH, int TW, int ph, int pw, float drop_p, uint32_t rng_stream, uint64_t seed,
+                  void* stream);
+int bsed_glu_bwd3_slabs(int C);
+int bsed_glu_bwd3_auto_g(int C);
+
 /* ------------------------------------------------------------------------------------------------
  * Clip-level domain discriminator glue (csrc/disc.hip); replaces Clip_Discriminator.forward
  * (src/models/CRNN_GRL.py:16-53), GradientReverseFunction (src/DA/grl.py:12-22) and the BCE of

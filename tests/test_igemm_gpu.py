@@ -174,3 +174,34 @@ def test_conv3x3_bf16x3_matches_fp64_reference(B, H, W, cin, co):
         dx, _ = ops.igemm3(_nhwc(dy).cuda(), wd3, cin, B, H, W, co, [(-a, -c) for a, c in ops.TAPS3x3])
         err = float((dx.cpu().double() - _nhwc(dref)).abs().max())
         assert err < 3e-5 * float(dref.abs().max()), err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,B,H,W,pool", [(32, 2, 24, 64, (2, 2)), (32, 1, 13, 16, (2, 2)), (32, 3, 27, 32, (1, 2)),
+                                          (32, 2, 627, 64, (2, 2)), (32, 1, 21, 64, (2, 2)), (64, 2, 313, 32, (1, 2)),
+                                          (64, 2, 27, 32, (1, 2)), (64, 1, 16, 16, (2, 2)), (64, 2, 9, 8, (1, 2))])
+def test_glu_backward_split_fp32_matches_fp32_fused_kernel(C, B, H, W, pool):
+    """csrc/glu3.hip (bf16 cores, split-fp32 operands, register-layout operands) vs csrc/glu_bwd.hip (fp32 cores) on
+    the same inputs, dropout on, partial tiles (H % TH != 0) and odd pooled extents included"""
+    from bsed_amd import ops
+    g = torch.Generator().manual_seed(C + H)
+    y = torch.randn(B, H, W, C, generator=g).cuda()
+    scale = (torch.rand(C, generator=g) + 0.5).cuda()
+    shift = (torch.randn(C, generator=g) * 0.3).cuda()
+    w = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+    bias = (torch.randn(C, generator=g) * 0.1).cuda()
+    ph, pw = pool
+    dpool = torch.randn(B, H // ph, W // pw, C, generator=g).cuda()
+    wfwd = ops.pack_weight(w, 1, C, C, 0, 1, C)
+    ref = ops.glu_bwd_fused(y, scale, shift, wfwd, w, bias, dpool, B, H, W, C, pool, 0.5, 103, 9)
+    got = ops.glu_bwd3(y, scale, shift, w, bias, dpool, B, H, W, C, pool, 0.5, 103, 9)
+
+    def finish(r):
+        gq, pdw, pdb, st, G, slabs = r
+        dw = torch.zeros(C, C, device="cuda")
+        ops.reduce_partials(pdw, G * slabs, 1, C, C, C, C, dw, 0, C, 1)
+        return gq, dw, pdb.sum(0)[0], st.sum(0)
+
+    for name, a, b in zip(("g", "dW", "db", "bn sums"), finish(got), finish(ref)):
+        err = float((a - b).norm() / b.norm())
+        assert err < 3e-5, (name, err)
