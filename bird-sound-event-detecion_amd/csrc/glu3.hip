@@ -356,6 +356,149 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? 3 : 2) void glu_bwd3_kernel(c
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Forward: y -> BatchNorm-apply -> Linear -> sigmoid gate -> Dropout -> AvgPool -> pooled, one pass over y.
+// GEMM1 as above; the epilogue works in the C layout where a lane holds, for its channel, four consecutive positions
+// per register group: the (1,2) and (2,2) pooling windows of a tile row are lane-local (the vertical partner of a
+// position sits 8 registers further at TW = 16, 4 at TW = 8, 2 at TW = 2), so pooling needs neither LDS nor shuffles.
+template <int C>
+__global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Params P) {
+  constexpr int NT = C / 32, KS = C / 16;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  bf16x8* WF = reinterpret_cast<bf16x8*>(smem_raw);
+  float* s_sc = reinterpret_cast<float*>(WF + NT * KS * 2 * 64);
+  float* s_sh = s_sc + C;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+
+  build_weight_frags<C>(P.w, WF, nullptr, tid);
+  for (int i = tid; i < C; i += G3_THREADS) { s_sc[i] = P.scale[i]; s_sh[i] = P.shift[i]; }
+  __syncthreads();
+
+  const int sph = P.ph >> 1, spw = P.pw >> 1;
+  const float inv_pool = 1.0f / (float)(P.ph * P.pw);
+  const uint32_t dkey = drop_key(P.rng_stream, P.seed), dthr = drop_threshold(P.drop_p);
+  const float dscale = P.drop_p > 0.f ? 1.0f / (1.0f - P.drop_p) : 1.0f;
+  // register distance of the vertical pooling partner (position m + TW): crow(r + dr) = crow(r) + TW
+  const int TW = P.TW;
+  float bias[NT], csc[NT], csh[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    bias[j] = P.bias[32 * j + li];
+    csc[j] = s_sc[32 * j + li]; csh[j] = s_sh[32 * j + li];
+  }
+
+  for (int tile0 = blockIdx.x; tile0 < P.ntiles; tile0 += gridDim.x) {
+    int tile = tile0;
+    const int tw_i = tile % P.tilesW; tile /= P.tilesW;
+    const int th_i = tile % P.tilesH;
+    const int nb = tile / P.tilesH;
+    const int th0 = th_i * P.TH, tw0 = tw_i * P.TW;
+    int lhv = 4 * lh;
+    asm volatile("" : "+v"(lhv));
+
+    f32x16 acc[NT];
+    {
+      bf16x8 a_hi[KS], a_lo[KS];
+      load_a_frags<C>(P, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const bf16x8 b_hi = WF[((j * KS + ks) * 2 + 0) * 64 + lane];
+          const bf16x8 b_lo = WF[((j * KS + ks) * 2 + 1) * 64 + lane];
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[ks], b_hi, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_lo, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_hi, acc[j], 0, 0, 0);
+        }
+    }
+
+    // ---- gate + dropout in place: acc <- (lin + b) * sigmoid(xn) * mask/(1-p)   (rows below the image -> 0)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float yv[4][NT], mk[4];
+      uint32_t posv[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int mm = wave * 32 + 8 * rg + lhv + rr;
+        const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (TW - 1));
+        mk[rr] = gh < P.H ? 1.0f : 0.0f;
+        posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) yv[rr][j] = P.y[posv[rr] + 32 * j];
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float xn = fmaf(yv[rr][j], csc[j], csh[j]);
+          const float keep = mk[rr] * drop_mul32(posv[rr] + 32 * j, dkey, dthr, dscale);
+          acc[j][4 * rg + rr] = (acc[j][4 * rg + rr] + bias[j]) * sigmoid_fast(xn) * keep;
+        }
+    }
+
+    // ---- average pooling, lane-local
+    if (P.ph == 1) {
+      // windows (m, m+1) [pw = 2] or single positions [pw = 1]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (P.pw == 2 && (r & 1)) continue;
+        const int mm = wave * 32 + crow3g(r, 0) + lhv;
+        const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (TW - 1));
+        const int gpw = gw >> spw;
+        if (gh < P.H && gpw < P.Wp) {
+          float* dst = P.pooled + (((size_t)nb * P.Hp + gh) * P.Wp + gpw) * C + li;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const float v = P.pw == 2 ? acc[j][r] + acc[j][r | 1] : acc[j][r];
+            dst[32 * j] = v * inv_pool;
+          }
+        }
+      }
+    } else {
+      // ph = 2: the partner row m + TW sits dr registers further (TW = 16 -> 8, TW = 8 -> 4, TW = 2 -> 2)
+      const int dr = TW == 16 ? 8 : (TW == 8 ? 4 : 2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mm = wave * 32 + crow3g(r, 0) + lhv;
+        const int lr = mm >> P.lgTW;  // tile row
+        const int gh = th0 + lr, gw = tw0 + (mm & (TW - 1));
+        const int gph = gh >> 1, gpw = gw >> spw;
+        const bool top = (lr & 1) == 0 && (P.pw == 1 || (gw & 1) == 0);
+        if (top && gph < P.Hp && gpw < P.Wp) {
+          float* dst = P.pooled + (((size_t)nb * P.Hp + gph) * P.Wp + gpw) * C + li;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            // (dynamic register offsets are resolved at compile time: r and dr take few values, selected below)
+            float v;
+            if (dr == 8) v = acc[j][r] + acc[j][(r + 8) & 15] + (P.pw == 2 ? acc[j][r | 1] + acc[j][((r + 8) & 15) | 1] : 0.f);
+            else if (dr == 4) v = acc[j][r] + acc[j][(r + 4) & 15] + (P.pw == 2 ? acc[j][r | 1] + acc[j][((r + 4) & 15) | 1] : 0.f);
+            else v = acc[j][r] + acc[j][(r + 2) & 15] + (P.pw == 2 ? acc[j][r | 1] + acc[j][((r + 2) & 15) | 1] : 0.f);
+            dst[32 * j] = v * inv_pool;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int C>
+static int launch_glu_fwd3(const Glu3Params& P, int G, hipStream_t s) {
+  constexpr int NT = C / 32, KS = C / 16;
+  const size_t smem = (size_t)NT * KS * 2 * 64 * 16 + 2 * C * sizeof(float);
+  static bool done = false;
+  if (!done) {
+    BSED_HIP(hipFuncSetAttribute((const void*)glu_fwd3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+  }
+  hipLaunchKernelGGL((glu_fwd3_kernel<C>), dim3(G), dim3(G3_THREADS), smem, s, P);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
 template <int C>
 static size_t glu_bwd3_smem() {
   constexpr int NT = C / 32, KS = C / 16;
@@ -413,4 +556,27 @@ extern "C" int bsed_glu_bwd3(const float* y, const float* scale, const float* sh
   hipStream_t s = (hipStream_t)stream;
   if (C == 64) return launch_glu_bwd3<64>(P, G, s);
   return launch_glu_bwd3<32>(P, G, s);
+}
+
+extern "C" int bsed_glu_fwd3_auto_g(int C) { (void)C; return 512; }
+
+extern "C" int bsed_glu_fwd3(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
+                             float* pooled, int G, int NB, int H, int W, int C, int TH, int TW, int ph, int pw,
+                             float drop_p, uint32_t rng_stream, uint64_t seed, void* stream) {
+  BSED_CHECK_ARG(y && scale && shift && w && bias && pooled, "bsed_glu_fwd3: null tensor");
+  BSED_CHECK_ARG(C == 32 || C == 64 || C == 128, "bsed_glu_fwd3: built for C in {32,64,128} (got %d)", C);
+  Glu3Params P;
+  int rc = fill_params(P, NB, H, W, C, TH, TW, ph, pw, "bsed_glu_fwd3");
+  if (rc) return rc;
+  BSED_CHECK_ARG(G > 0 && G <= P.ntiles, "bsed_glu_fwd3: G must be in 1..%d tiles", P.ntiles);
+  BSED_CHECK_ARG(pw == 1 || TW >= 2, "bsed_glu_fwd3: horizontal pooling needs TW >= 2");
+  BSED_CHECK_ARG(ph == 1 || ((TW == 16 || TW == 8 || TW == 2) && TH % 2 == 0),
+                 "bsed_glu_fwd3: vertical pooling is lane-local only for TW in {2,8,16} (got %d)", TW);
+  P.y = y; P.scale = scale; P.shift = shift; P.w = w; P.bias = bias; P.dpool = nullptr;
+  P.g = nullptr; P.part_dw = nullptr; P.part_db = nullptr; P.part_st = nullptr; P.pooled = pooled;
+  P.drop_p = drop_p; P.rng_stream = rng_stream; P.seed = seed;
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 128) return launch_glu_fwd3<128>(P, G, s);
+  if (C == 64) return launch_glu_fwd3<64>(P, G, s);
+  return launch_glu_fwd3<32>(P, G, s);
 }

@@ -265,6 +265,9 @@ class CRNN(_FlatModule):
                 # 4 FLOP/B: HBM-bound streaming kernel instead of the MFMA tile kernel (csrc/glu_small.hip)
                 pooled = ops.glu16_fwd(y, scale, shift, glu.weight, glu.bias, B, Hh, Ww, (ph, pw), drop, 100 + i,
                                        self.seed)
+            elif self.conv_mode == "bf16x3" and self.glu3 and ops.glu_fwd3_supported(Ww, co, (ph, pw)):
+                pooled = ops.glu_fwd3(y, scale, shift, glu.weight, glu.bias, B, Hh, Ww, co, (ph, pw), drop, 100 + i,
+                                      self.seed)
             else:
                 wg = ops.pack_weight(glu.weight, 1, co, co, 0, 1, co)
                 pooled, _ = ops.igemm(y, wg, co, B, Hh, Ww, co, bias=glu.bias, epilogue=ops.EPI_GLU_POOL,

@@ -298,6 +298,25 @@ def glu_bwd_fused(y, scale, shift, wfwd, w, bias, dpool, B, H, W, C, pool, drop_
     return g, part_dw, part_db, part_st, G, slabs
 
 
+def glu_fwd3_supported(W, C, pool):
+    TH, TW = tile_for(W)
+    return C in (32, 64, 128) and (pool[1] == 1 or TW >= 2) and (pool[0] == 1 or (TW in (2, 8, 16) and TH % 2 == 0))
+
+
+def glu_fwd3(y, scale, shift, w, bias, B, H, W, C, pool, drop_p, rng_stream, seed):
+    """split-fp32 GLU forward: BN-apply -> Linear -> gate -> dropout -> avg-pool in one pass over y"""
+    ph, pw = pool
+    TH, TW = tile_for(W)
+    ntiles = B * ((H + TH - 1) // TH) * (W // TW)
+    G = int(min(ntiles, L.lib().bsed_glu_fwd3_auto_g(C)))
+    out = torch.empty((B, H // ph, W // pw, C), device=y.device, dtype=torch.float32)
+    _launch((f"glu_fwd3_kernel<{C}>", 1, C, C, H, W), 2.0 * B * H * W * C * C,
+            lambda: L.call("bsed_glu_fwd3", L.ptr(y), L.ptr(scale), L.ptr(shift), _fp(_dp(w)), _fp(_dp(bias)),
+                           L.ptr(out), _i(G), _i(B), _i(H), _i(W), _i(C), _i(TH), _i(TW), _i(ph), _i(pw),
+                           ctypes.c_float(drop_p), ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream()))
+    return out
+
+
 def glu_bwd3(y, scale, shift, w, bias, dpool, B, H, W, C, pool, drop_p, rng_stream, seed):
     """split-fp32 fused GLU backward (C in {32,64}); returns like glu_bwd_fused"""
     ph, pw = pool

@@ -219,6 +219,13 @@ int bsed_glu_bwd3(const float* y, const float* scale, const float* shift, const 
                   void* stream);
 int bsed_glu_bwd3_slabs(int C);
 int bsed_glu_bwd3_auto_g(int C);
+/* Forward of the same stage in the split-fp32 mode, C in {32,64,128}: y (NB,H,W,C) -> pooled (NB,H/ph,W/pw,C);
+ * replaces bsed_igemm(BSED_EPI_GLU_POOL) (GLU.forward + nn.Dropout + nn.AvgPool2d, src/models/CNN.py:5-16,59-67).
+ * Vertical pooling (ph = 2) is supported for tile widths TW in {2,8,16}. */
+int bsed_glu_fwd3(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
+                  float* pooled, int G, int NB, int H, int W, int C, int TH, int TW, int ph, int pw, float drop_p,
+                  uint32_t rng_stream, uint64_t seed, void* stream);
+int bsed_glu_fwd3_auto_g(int C);
 
 /* ------------------------------------------------------------------------------------------------
  * Clip-level domain discriminator glue (csrc/disc.hip); replaces Clip_Discriminator.forward

@@ -205,3 +205,31 @@ def test_glu_backward_split_fp32_matches_fp32_fused_kernel(C, B, H, W, pool):
     for name, a, b in zip(("g", "dW", "db", "bn sums"), finish(got), finish(ref)):
         err = float((a - b).norm() / b.norm())
         assert err < 3e-5, (name, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,B,H,W,pool", [(32, 2, 24, 64, (2, 2)), (32, 1, 13, 16, (2, 2)), (32, 2, 627, 64, (2, 2)),
+                                          (64, 2, 27, 32, (1, 2)), (64, 1, 17, 8, (2, 2)), (128, 2, 21, 16, (1, 2)),
+                                          (128, 3, 9, 2, (1, 2)), (128, 1, 40, 4, (1, 2)), (64, 2, 10, 2, (2, 2)),
+                                          (128, 1, 12, 8, (1, 1))])
+def test_glu_forward_split_fp32_matches_torch(C, B, H, W, pool):
+    """csrc/glu3.hip forward vs torch (dropout off) and vs the fp32-core kernel (dropout on: same masks)"""
+    from bsed_amd import ops
+    g = torch.Generator().manual_seed(C + H + W)
+    y = torch.randn(B, H, W, C, generator=g).cuda()
+    scale = (torch.rand(C, generator=g) + 0.5).cuda()
+    shift = (torch.randn(C, generator=g) * 0.3).cuda()
+    w = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+    bias = (torch.randn(C, generator=g) * 0.1).cuda()
+    assert ops.glu_fwd3_supported(W, C, pool)
+    got = ops.glu_fwd3(y, scale, shift, w, bias, B, H, W, C, pool, 0.0, 101, 5)
+    xn = y * scale + shift
+    res = (xn @ w.t() + bias) * torch.sigmoid(xn)
+    ref = torch.nn.functional.avg_pool2d(res.permute(0, 3, 1, 2), pool).permute(0, 2, 3, 1)
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    wpk = ops.pack_weight(w, 1, C, C, 0, 1, C)
+    ref_d, _ = ops.igemm(y, wpk, C, B, H, W, C, bias=bias, epilogue=ops.EPI_GLU_POOL, a_scale=scale, a_shift=shift,
+                         e_src=y, e_scale=scale, e_shift=shift, pool=pool, drop_p=0.5, rng_stream=101, seed=5)
+    got_d = ops.glu_fwd3(y, scale, shift, w, bias, B, H, W, C, pool, 0.5, 101, 5)
+    assert float((got_d - ref_d).abs().max()) < 4e-5 * max(1.0, float(ref_d.abs().max()))
