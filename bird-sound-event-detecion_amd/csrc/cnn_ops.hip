@@ -2,11 +2,11 @@
 //
 //   conv0_fwd_kernel     first conv (Cin = 1): a 9-tap stencil, no MFMA          [src/models/CNN.py:46-47, i = 0]
 //   conv0_wgrad_kernel   its weight gradient (thread-private 9 x CO accumulators)
-//   stats_reduce_kernel  per-tile (sum, sumsq) partials -> fp64 per-channel sums
-//   bn_finalize_kernel   BatchNorm2d(eps, momentum) train-mode statistics -> scale/shift + running stats
+//   stats_chunk / stats_finish  per-tile partial sums -> fp64 chunk sums -> totals + BatchNorm finalize (scale/shift,
+//                        running stats) / BatchNorm-backward coefficients / bias gradients
 //                                                                               [src/models/CNN.py:49]
 //   bn_eval_kernel       eval-mode scale/shift from the running statistics
-//   bn_bwd_finalize / bn_bwd_apply   BatchNorm backward as one affine map d_y = A g + B (y-mean) + C
+//   bn_bwd_apply         BatchNorm backward as one affine map d_y = A g + B (y-mean) + C
 //   colsum / bias helpers
 #include "bsed_common.h"
 #include "../../include/bsed.h"
@@ -150,64 +150,6 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// partial[tile][2][C] (fp32) -> sums[chunk][2][C] (fp64); a second call with ntiles = nchunks and
-// in_double = 1 finishes the reduction.
-__global__ __launch_bounds__(256) void stats_reduce_kernel(const void* __restrict__ partial, int in_double,
-                                                           long ntiles, int C, double* __restrict__ out) {
-  __shared__ double sm[256];
-  const int tid = threadIdx.x;
-  const int cl = tid & 31, g = tid >> 5;  // 32 channels x 8 tile groups
-  const int c = blockIdx.y * 32 + cl;
-  const long chunk = blockIdx.x, nchunks = gridDim.x;
-  const long per = (ntiles + nchunks - 1) / nchunks;
-  const long t0 = chunk * per, t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
-  for (int which = 0; which < 2; ++which) {
-    double s = 0.0;
-    if (c < C) {
-      if (in_double) {
-        const double* p = reinterpret_cast<const double*>(partial);
-        for (long t = t0 + g; t < t1; t += 8) s += p[(t * 2 + which) * C + c];
-      } else {
-        const float* p = reinterpret_cast<const float*>(partial);
-        for (long t = t0 + g; t < t1; t += 8) s += (double)p[(t * 2 + which) * C + c];
-      }
-    }
-    __syncthreads();
-    sm[tid] = s;
-    __syncthreads();
-    if (g == 0 && c < C) {
-      double r = 0.0;
-      for (int gg = 0; gg < 8; ++gg) r += sm[gg * 32 + cl];
-      out[(chunk * 2 + which) * C + c] = r;
-    }
-  }
-}
-
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, double count, float eps, float momentum,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   long long* __restrict__ num_batches_tracked, float* __restrict__ mean_out,
-                                   float* __restrict__ invstd_out, float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
-  if (c >= C) return;
-  const double mean = sums[c] / count;
-  double var = sums[C + c] / count - mean * mean;
-  if (var < 0) var = 0;
-  const double invstd = 1.0 / sqrt(var + (double)eps);
-  mean_out[c] = (float)mean;
-  invstd_out[c] = (float)invstd;
-  const float sc = gamma[c] * (float)invstd;
-  scale[c] = sc;
-  shift[c] = beta[c] - (float)mean * sc;
-  if (running_mean) {
-    const double unbiased = count > 1 ? var * count / (count - 1) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-  }
-}
-
 __global__ void bn_eval_kernel(int C, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
                                const float* __restrict__ running_mean, const float* __restrict__ running_var,
                                float* __restrict__ scale, float* __restrict__ shift) {
@@ -219,28 +161,6 @@ __global__ void bn_eval_kernel(int C, float eps, const float* __restrict__ gamma
 }
 
 // sums = (sum g, sum g*y) -> dgamma, dbeta and the coefficients of d_y = A g + B (y - mean) + Cc
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int C, double count,
-                                       const float* __restrict__ gamma, const float* __restrict__ mean,
-                                       const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double sg = sums[c], sgy = sums[C + c];
-  const double m = mean[c], is = invstd[c];
-  const double dgam = (sgy - m * sg) * is;
-  const double A = (double)gamma[c] * is;
-  coef[c] = (float)A;
-  coef[C + c] = (float)(-A * is * dgam / count);
-  coef[2 * C + c] = (float)(-A * sg / count);
-  if (accumulate) {
-    dgamma[c] += (float)dgam;
-    dbeta[c] += (float)sg;
-  } else {
-    dgamma[c] = (float)dgam;
-    dbeta[c] = (float)sg;
-  }
-}
-
 __global__ void bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ coef,
                                     const float* __restrict__ mean, long n4, int C) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -259,13 +179,99 @@ __global__ void bn_bwd_apply_kernel(float* __restrict__ g, const float* __restri
   }
 }
 
-// dst[c] (+)= sums[which][c]
-__global__ void sums_to_grad_kernel(const double* __restrict__ sums, int C, int which, float* __restrict__ dst,
-                                    int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float v = (float)sums[which * C + c];
-  dst[c] = accumulate ? dst[c] + v : v;
+// ---------------------------------------------------------------------------------------------
+// Reduction + finalize in TWO launches: the chunk workgroups write fp64 partial sums, then one workgroup per 32
+// channels adds the chunks in a fixed order and runs the finalize step (BatchNorm scale/shift + running statistics,
+// BatchNorm-backward coefficients, or a bias gradient) in the same kernel.  (A single launch whose last workgroup
+// finishes was measured 4x SLOWER: the device-scope release fence writes back the whole L2, which is full of the
+// activations the producer kernel just wrote.)
+enum { FIN_BN_FWD = 0, FIN_BN_BWD = 1, FIN_TO_GRAD = 2 };
+struct StatsFin {
+  int mode, which, accumulate;
+  double count; float eps, momentum;
+  const float* gamma; const float* beta; const float* mean; const float* invstd;
+  float* running_mean; float* running_var; long long* nbt;
+  float* mean_out; float* invstd_out; float* scale; float* shift;
+  float* dgamma; float* dbeta; float* coef; float* dst;
+};
+
+__device__ __forceinline__ void stats_finish(const StatsFin& F, int C, int c, double s0, double s1) {
+  if (F.mode == FIN_BN_FWD) {
+    if (c == 0 && F.nbt) *F.nbt += 1;
+    const double mean = s0 / F.count;
+    double var = s1 / F.count - mean * mean;
+    if (var < 0) var = 0;
+    const double invstd = 1.0 / sqrt(var + (double)F.eps);
+    F.mean_out[c] = (float)mean;
+    F.invstd_out[c] = (float)invstd;
+    const float sc = F.gamma[c] * (float)invstd;
+    F.scale[c] = sc;
+    F.shift[c] = F.beta[c] - (float)mean * sc;
+    if (F.running_mean) {
+      const double unbiased = F.count > 1 ? var * F.count / (F.count - 1) : var;
+      F.running_mean[c] = (1.f - F.momentum) * F.running_mean[c] + F.momentum * (float)mean;
+      F.running_var[c] = (1.f - F.momentum) * F.running_var[c] + F.momentum * (float)unbiased;
+    }
+  } else if (F.mode == FIN_BN_BWD) {
+    const double sg = s0, sgy = s1;
+    const double m = F.mean[c], is = F.invstd[c];
+    const double dgam = (sgy - m * sg) * is;
+    const double A = (double)F.gamma[c] * is;
+    F.coef[c] = (float)A;
+    F.coef[C + c] = (float)(-A * is * dgam / F.count);
+    F.coef[2 * C + c] = (float)(-A * sg / F.count);
+    if (F.accumulate) { F.dgamma[c] += (float)dgam; F.dbeta[c] += (float)sg; }
+    else { F.dgamma[c] = (float)dgam; F.dbeta[c] = (float)sg; }
+  } else {
+    const float v = (float)(F.which ? s1 : s0);
+    F.dst[c] = F.accumulate ? F.dst[c] + v : v;
+  }
+}
+
+__global__ __launch_bounds__(256) void stats_chunk_kernel(const float* __restrict__ partial, long ntiles, int C,
+                                                          double* __restrict__ chunks) {
+  __shared__ double sm[2][256];
+  const int tid = threadIdx.x;
+  const int cl = tid & 31, g = tid >> 5;  // 32 channels x 8 tile groups
+  const int c = blockIdx.y * 32 + cl;
+  const long chunk = blockIdx.x, nchunks = gridDim.x;
+  const long per = (ntiles + nchunks - 1) / nchunks;
+  const long t0 = chunk * per, t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C)
+    for (long t = t0 + g; t < t1; t += 8) {
+      s0 += (double)partial[(t * 2 + 0) * C + c];
+      s1 += (double)partial[(t * 2 + 1) * C + c];
+    }
+  sm[0][tid] = s0; sm[1][tid] = s1;
+  __syncthreads();
+  if (g == 0 && c < C) {
+    double r0 = 0.0, r1 = 0.0;
+    for (int gg = 0; gg < 8; ++gg) { r0 += sm[0][gg * 32 + cl]; r1 += sm[1][gg * 32 + cl]; }
+    chunks[(chunk * 2 + 0) * C + c] = r0;
+    chunks[(chunk * 2 + 1) * C + c] = r1;
+  }
+}
+
+__global__ __launch_bounds__(256) void stats_finish_kernel(const double* __restrict__ chunks, int nchunks, int C,
+                                                           const StatsFin F) {
+  __shared__ double sm[2][256];
+  const int tid = threadIdx.x;
+  const int cl = tid & 31, g = tid >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C)
+    for (int k = g; k < nchunks; k += 8) {
+      s0 += chunks[((size_t)k * 2 + 0) * C + c];
+      s1 += chunks[((size_t)k * 2 + 1) * C + c];
+    }
+  sm[0][tid] = s0; sm[1][tid] = s1;
+  __syncthreads();
+  if (g == 0 && c < C) {
+    double r0 = 0.0, r1 = 0.0;
+    for (int gg = 0; gg < 8; ++gg) { r0 += sm[0][gg * 32 + cl]; r1 += sm[1][gg * 32 + cl]; }
+    stats_finish(F, C, c, r0, r1);
+  }
 }
 
 // per-block column sums of a (M, C) matrix with row pitch: part[blk][2][C] (slot 1 = 0), fed to stats_reduce
@@ -338,16 +344,12 @@ extern "C" int bsed_conv0_wgrad(const float* x, const float* dy, const float* y,
 
 #define STATS_CHUNKS 128
 
-extern "C" size_t bsed_stats_scratch_bytes(int C) { return (size_t)(STATS_CHUNKS + 1) * 2 * C * sizeof(double); }
+extern "C" size_t bsed_stats_scratch_bytes(int C) { return (size_t)STATS_CHUNKS * 2 * C * sizeof(double); }
 
-// partial (ntiles,2,C) fp32 -> sums (2,C) fp64 at scratch + STATS_CHUNKS*2*C
-static int stats_reduce(const float* partial, long ntiles, int C, double* scratch, hipStream_t s) {
+static int stats_reduce_finish(const float* partial, long ntiles, int C, double* scratch, const StatsFin& F, hipStream_t s) {
   const int chunks = (int)std::min<long>(STATS_CHUNKS, ntiles);
-  dim3 g1(chunks, ceil_div(C, 32));
-  hipLaunchKernelGGL(stats_reduce_kernel, g1, dim3(256), 0, s, (const void*)partial, 0, ntiles, C, scratch);
-  dim3 g2(1, ceil_div(C, 32));
-  hipLaunchKernelGGL(stats_reduce_kernel, g2, dim3(256), 0, s, (const void*)scratch, 1, (long)chunks, C,
-                     scratch + (size_t)STATS_CHUNKS * 2 * C);
+  hipLaunchKernelGGL(stats_chunk_kernel, dim3(chunks, ceil_div(C, 32)), dim3(256), 0, s, partial, ntiles, C, scratch);
+  hipLaunchKernelGGL(stats_finish_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, s, scratch, chunks, C, F);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }
@@ -360,13 +362,11 @@ extern "C" int bsed_bn_finalize(const float* partial, long ntiles, int C, double
   BSED_CHECK_ARG(ntiles > 0 && C > 0 && count > 0, "bsed_bn_finalize: bad shape");
   hipStream_t s = (hipStream_t)stream;
   double* sc = (double*)scratch;
-  int rc = stats_reduce(partial, ntiles, C, sc, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, sc + (size_t)STATS_CHUNKS * 2 * C, C,
-                     count, eps, momentum, gamma, beta, running_mean, running_var, num_batches_tracked, mean, invstd,
-                     scale, shift);
-  BSED_LAUNCH_CHECK();
-  return BSED_OK;
+  StatsFin F = {};
+  F.mode = FIN_BN_FWD; F.count = count; F.eps = eps; F.momentum = momentum; F.gamma = gamma; F.beta = beta;
+  F.running_mean = running_mean; F.running_var = running_var; F.nbt = num_batches_tracked;
+  F.mean_out = mean; F.invstd_out = invstd; F.scale = scale; F.shift = shift;
+  return stats_reduce_finish(partial, ntiles, C, sc, F, s);
 }
 
 extern "C" int bsed_bn_eval(int C, float eps, const float* gamma, const float* beta, const float* running_mean,
@@ -386,10 +386,11 @@ extern "C" int bsed_bn_bwd(const float* partial, long ntiles, int C, double coun
   BSED_CHECK_ARG(ntiles > 0 && C > 0 && C % 4 == 0 && n_elems % C == 0, "bsed_bn_bwd: bad shape");
   hipStream_t s = (hipStream_t)stream;
   double* sc = (double*)scratch;
-  int rc = stats_reduce(partial, ntiles, C, sc, s);
+  StatsFin F = {};
+  F.mode = FIN_BN_BWD; F.count = count; F.gamma = gamma; F.mean = mean; F.invstd = invstd;
+  F.dgamma = dgamma; F.dbeta = dbeta; F.accumulate = accumulate; F.coef = coef;
+  int rc = stats_reduce_finish(partial, ntiles, C, sc, F, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s,
-                     sc + (size_t)STATS_CHUNKS * 2 * C, C, count, gamma, mean, invstd, dgamma, dbeta, accumulate, coef);
   if (!g_inout) {  // coefficients only: the consumer applies the affine map on load (bsed_conv0_wgrad)
     BSED_LAUNCH_CHECK();
     return BSED_OK;
@@ -407,12 +408,9 @@ extern "C" int bsed_stats_to_grad(const float* partial, long ntiles, int C, int 
   BSED_CHECK_ARG(partial && dst && scratch && ntiles > 0 && C > 0 && (which == 0 || which == 1), "bsed_stats_to_grad: bad argument");
   hipStream_t s = (hipStream_t)stream;
   double* sc = (double*)scratch;
-  int rc = stats_reduce(partial, ntiles, C, sc, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(sums_to_grad_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, sc + (size_t)STATS_CHUNKS * 2 * C, C,
-                     which, dst, accumulate);
-  BSED_LAUNCH_CHECK();
-  return BSED_OK;
+  StatsFin F = {};
+  F.mode = FIN_TO_GRAD; F.which = which; F.dst = dst; F.accumulate = accumulate;
+  return stats_reduce_finish(partial, ntiles, C, sc, F, s);
 }
 
 // dst[c] (+)= sum_r in[r][c]; part must hold G*2*C floats

@@ -807,6 +807,8 @@ static int wgrad_prepare(const BsedWgradDesc* desc, WgradParams& P, size_t& smem
   P.CC = 32;
   for (int cand = (d.ntaps == 1 ? 128 : 64); cand >= 32; cand >>= 1)
     if (d.CINP % cand == 0) { P.CC = cand; break; }
+  // tall narrow tiles (W = 2: 66 x 4 halo patch) would leave a single workgroup per CU with 64-channel chunks
+  if (mode3 && d.ntaps > 1 && P.CC > 32 && (size_t)P.PP * P.CC * 4 + (size_t)2 * 32 * W3_RD * 2 > 80 * 1024) P.CC = 32;
   BSED_CHECK_ARG(d.CINP % P.CC == 0 && d.CINP / P.CC <= 65535, "bsed_wgrad: CINP must be a multiple of 32");
   P.lgc4 = ilog2_exact(P.CC / 4);
   P.nct = P.CC / 32;

@@ -160,7 +160,8 @@ int bsed_conv0_num_tiles(int NB, int H, int W);
  * coefficients-only mode) is applied on load: the first block's d_y never touches HBM. */
 int bsed_conv0_wgrad(const float* x, const float* dy, const float* y, const float* coef, const float* mean,
                      float* part, int G, int NB, int H, int W, int CO, void* stream);
-/* fp64 scratch needed by the statistics reductions below */
+/* fp64 scratch needed by the statistics reductions below (not to be shared by calls running concurrently on two
+ * streams) */
 size_t bsed_stats_scratch_bytes(int C);
 /* BatchNorm2d(eps, momentum) in train mode (src/models/CNN.py:49): per-tile partials -> batch mean /
  * invstd, scale = gamma*invstd, shift = beta - mean*scale; running stats (unbiased var) and
