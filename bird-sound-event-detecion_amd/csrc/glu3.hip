@@ -357,6 +357,224 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? 3 : 2) void glu_bwd3_kernel(c
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// C = 128: the same backward WITHOUT the in-kernel weight gradient.  128 x 128 accumulators per wave do not fit in
+// registers, so d_lin is also written to HBM and dW = d_lin^T xn runs as a 1-tap bsed_wgrad3 afterwards (BatchNorm
+// applied on load there).  Both weight operands (hi|lo: 128 KB) sit in LDS, copied from a table that
+// glu3_pack_frags_kernel builds once per call; d_lin crosses to the A layout of GEMM2 through a wave-private tile
+// that holds ONE 32-channel quarter at a time (GEMM2's K loop is split in four), which keeps LDS at 148 KB.
+__global__ void glu3_pack_frags_kernel(const float* __restrict__ w, bf16x8* __restrict__ table) {
+  constexpr int C = 128, NT = 4, KS = 8;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= NT * KS * 64) return;
+  const int lane = f & 63, li = lane & 31, lh = lane >> 5;
+  const int ks = (f >> 6) % KS, j = (f >> 6) / KS;
+  bf16x8* WF = table;
+  bf16x8* WB = table + NT * KS * 2 * 64;
+  float v[8];
+  bf16x8 hi, lo;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = w[(size_t)(32 * j + li) * C + 16 * ks + 8 * lh + q];
+  split_pack8(v, hi, lo);
+  WF[((j * KS + ks) * 2 + 0) * 64 + lane] = hi;
+  WF[((j * KS + ks) * 2 + 1) * 64 + lane] = lo;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = w[(size_t)(16 * ks + 8 * lh + q) * C + 32 * j + li];
+  split_pack8(v, hi, lo);
+  WB[((j * KS + ks) * 2 + 0) * 64 + lane] = hi;
+  WB[((j * KS + ks) * 2 + 1) * 64 + lane] = lo;
+}
+
+__global__ __launch_bounds__(G3_THREADS, 1) void glu_bwd3n_kernel(const Glu3Params P, const bf16x8* __restrict__ table,
+                                                                  float* __restrict__ dlin) {
+  constexpr int C = 128, NT = 4, KS = 8;
+  constexpr int DQ = 2 * 32 + 8;  // ushorts per row of the quarter tile: 32 hi | 32 lo | 8 pad (144 B = 9 x 16 B)
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  bf16x8* WF = reinterpret_cast<bf16x8*>(smem_raw);
+  bf16x8* WB = WF + NT * KS * 2 * 64;
+  float* s_sc = reinterpret_cast<float*>(WB + NT * KS * 2 * 64);
+  float* s_sh = s_sc + C;
+  unsigned short* Dall = reinterpret_cast<unsigned short*>(s_sh + C);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  unsigned short* D = Dall + wave * 32 * DQ;  // wave-private
+
+  for (int i = tid; i < 2 * NT * KS * 2 * 64; i += G3_THREADS) WF[i] = table[i];
+  for (int i = tid; i < C; i += G3_THREADS) { s_sc[i] = P.scale[i]; s_sh[i] = P.shift[i]; }
+  __syncthreads();
+
+  const int sph = P.ph >> 1, spw = P.pw >> 1;
+  const float inv_pool = 1.0f / (float)(P.ph * P.pw);
+  const uint32_t dkey = drop_key(P.rng_stream, P.seed), dthr = drop_threshold(P.drop_p);
+  const float dscale = P.drop_p > 0.f ? 1.0f / (1.0f - P.drop_p) : 1.0f;
+
+  float bias[NT], csc[NT], csh[NT], sdb[NT], sgs[NT], sgy[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    bias[j] = P.bias[32 * j + li];
+    csc[j] = s_sc[32 * j + li]; csh[j] = s_sh[32 * j + li];
+    sdb[j] = 0.f; sgs[j] = 0.f; sgy[j] = 0.f;
+  }
+
+  for (int tile0 = blockIdx.x; tile0 < P.ntiles; tile0 += gridDim.x) {
+    int tile = tile0;
+    const int tw_i = tile % P.tilesW; tile /= P.tilesW;
+    const int th_i = tile % P.tilesH;
+    const int nb = tile / P.tilesH;
+    const int th0 = th_i * P.TH, tw0 = tw_i * P.TW;
+    int lhv = 4 * lh;
+    asm volatile("" : "+v"(lhv));
+
+    // ---- GEMM1: lin = xn W^T
+    f32x16 acc[NT];
+    {
+      bf16x8 a_hi[KS], a_lo[KS];
+      load_a_frags<C>(P, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const bf16x8 b_hi = WF[((j * KS + ks) * 2 + 0) * 64 + lane];
+          const bf16x8 b_lo = WF[((j * KS + ks) * 2 + 1) * 64 + lane];
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[ks], b_hi, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_lo, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_hi, acc[j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue 1: gate term -> accumulators, d_lin -> HBM (for the weight-gradient pass) and, split into bf16
+    // hi/lo pairs, kept in registers until its 32-channel quarter of GEMM2 comes up
+    uint32_t dph[NT][8], dpl[NT][8];  // packed (r even | r odd << 16)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float dv[4][NT], yv[4][NT], mk[4];
+      uint32_t posv[4];
+      float* dlrow[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int mm = wave * 32 + 8 * rg + lhv + rr;
+        const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (P.TW - 1));
+        const int gph = gh >> sph, gpw = gw >> spw;
+        mk[rr] = (gh < P.H && gph < P.Hp && gpw < P.Wp) ? inv_pool : 0.f;
+        posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
+        dlrow[rr] = gh < P.H ? dlin + posv[rr] : g3_sink + li;
+        const uint32_t dpo = ((uint32_t)(nb * P.Hp + min(gph, P.Hp - 1)) * (uint32_t)P.Wp + min(gpw, P.Wp - 1)) * C + li;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          dv[rr][j] = P.dpool[dpo + 32 * j];
+          yv[rr][j] = P.y[posv[rr] + 32 * j];
+        }
+      }
+#pragma unroll
+      for (int rp = 0; rp < 2; ++rp)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          float dl2[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int rr = 2 * rp + e, r = 4 * rg + rr;
+            const float xn = fmaf(yv[rr][j], csc[j], csh[j]);
+            const float sg = sigmoid_fast(xn);
+            const float lin = acc[j][r] + bias[j];
+            const float dres = dv[rr][j] * mk[rr] * drop_mul32(posv[rr] + 32 * j, dkey, dthr, dscale);
+            const float dl = dres * sg;
+            acc[j][r] = dres * lin * sg * (1.0f - sg);
+            sdb[j] += dl;
+            dlrow[rr][32 * j] = dl;
+            dl2[e] = dl;
+          }
+          split_pack2(dl2[0], dl2[1], dph[j][2 * rg + rp], dpl[j][2 * rg + rp]);
+        }
+    }
+
+    // ---- GEMM2 in four K quarters: g = d_lin W + gate term (already in acc)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = 2 * i;  // packed pair (r, r+1): rows crow(r), crow(r)+1
+        const int row = 8 * (r >> 2) + lhv + (r & 3);
+        D[row * DQ + li] = (unsigned short)(dph[q][i] & 0xFFFFu);
+        D[(row + 1) * DQ + li] = (unsigned short)(dph[q][i] >> 16);
+        D[row * DQ + 32 + li] = (unsigned short)(dpl[q][i] & 0xFFFFu);
+        D[(row + 1) * DQ + 32 + li] = (unsigned short)(dpl[q][i] >> 16);
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int ks = 2 * q + k2;
+        const bf16x8 d_hi = *reinterpret_cast<const bf16x8*>(D + li * DQ + 16 * k2 + 8 * lh);
+        const bf16x8 d_lo = *reinterpret_cast<const bf16x8*>(D + li * DQ + 32 + 16 * k2 + 8 * lh);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const bf16x8 b_hi = WB[((j * KS + ks) * 2 + 0) * 64 + lane];
+          const bf16x8 b_lo = WB[((j * KS + ks) * 2 + 1) * 64 + lane];
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_lo, b_hi, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_hi, b_lo, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_hi, b_hi, acc[j], 0, 0, 0);
+        }
+      }
+      wave_lds_fence();
+    }
+
+    // ---- epilogue 2: write g, BatchNorm-backward sums (y re-read: cache-hot)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float yv[4][NT], okf[4];
+      uint32_t posv[4];
+      float* gdst[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int mm = wave * 32 + 8 * rg + lhv + rr;
+        const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (P.TW - 1));
+        okf[rr] = gh < P.H ? 1.0f : 0.0f;
+        posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
+        gdst[rr] = gh < P.H ? P.g + posv[rr] : g3_sink + li;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) yv[rr][j] = P.y[posv[rr] + 32 * j];
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float gv = acc[j][4 * rg + rr] * okf[rr];
+          gdst[rr][32 * j] = gv;
+          sgs[j] += gv;
+          sgy[j] = fmaf(gv, yv[rr][j], sgy[j]);
+        }
+    }
+  }
+
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(Dall);  // [4 waves][3][C] = 6 KB of the 18 KB tile area
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const float a = sdb[j] + __shfl_xor(sdb[j], 32, 64);
+    const float b = sgs[j] + __shfl_xor(sgs[j], 32, 64);
+    const float c = sgy[j] + __shfl_xor(sgy[j], 32, 64);
+    if (lh == 0) {
+      red[(wave * 3 + 0) * C + 32 * j + li] = a;
+      red[(wave * 3 + 1) * C + 32 * j + li] = b;
+      red[(wave * 3 + 2) * C + 32 * j + li] = c;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 3 * C; e += G3_THREADS) {
+    const int which = e / C, n = e % C;
+    const float s = red[(0 * 3 + which) * C + n] + red[(1 * 3 + which) * C + n] + red[(2 * 3 + which) * C + n] +
+                    red[(3 * 3 + which) * C + n];
+    if (which == 0) {
+      P.part_db[((size_t)blockIdx.x * 2 + 0) * C + n] = s;
+      P.part_db[((size_t)blockIdx.x * 2 + 1) * C + n] = 0.f;
+    } else {
+      P.part_st[((size_t)blockIdx.x * 2 + (which - 1)) * C + n] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Forward: y -> BatchNorm-apply -> Linear -> sigmoid gate -> Dropout -> AvgPool -> pooled, one pass over y.
 // GEMM1 as above; the epilogue works in the C layout where a lane holds, for its channel, four consecutive positions
 // per register group: the (1,2) and (2,2) pooling windows of a tile row are lane-local (the vertical partner of a
@@ -579,4 +797,35 @@ extern "C" int bsed_glu_fwd3(const float* y, const float* scale, const float* sh
   if (C == 128) return launch_glu_fwd3<128>(P, G, s);
   if (C == 64) return launch_glu_fwd3<64>(P, G, s);
   return launch_glu_fwd3<32>(P, G, s);
+}
+
+// C = 128: g, d_lin (for the separate weight-gradient pass), db and BatchNorm-backward partials.  frag_table: 128 KB
+// of device scratch that this call fills (bsed_glu_bwd3n_table_bytes()).
+extern "C" size_t bsed_glu_bwd3n_table_bytes(void) { return (size_t)2 * 4 * 8 * 2 * 64 * 16; }
+
+extern "C" int bsed_glu_bwd3n(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
+                              const float* dpool, float* g, float* dlin, float* part_db, float* part_st,
+                              void* frag_table, int G, int NB, int H, int W, int C, int TH, int TW, int ph, int pw,
+                              float drop_p, uint32_t rng_stream, uint64_t seed, void* stream) {
+  BSED_CHECK_ARG(y && scale && shift && w && bias && dpool && g && dlin && part_db && part_st && frag_table,
+                 "bsed_glu_bwd3n: null tensor");
+  BSED_CHECK_ARG(C == 128, "bsed_glu_bwd3n: built for C = 128 (got %d)", C);
+  Glu3Params P;
+  int rc = fill_params(P, NB, H, W, C, TH, TW, ph, pw, "bsed_glu_bwd3n");
+  if (rc) return rc;
+  BSED_CHECK_ARG(G > 0 && G <= P.ntiles, "bsed_glu_bwd3n: G must be in 1..%d tiles", P.ntiles);
+  P.y = y; P.scale = scale; P.shift = shift; P.w = w; P.bias = bias; P.dpool = dpool;
+  P.g = g; P.part_dw = nullptr; P.part_db = part_db; P.part_st = part_st; P.pooled = nullptr;
+  P.drop_p = drop_p; P.rng_stream = rng_stream; P.seed = seed;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(glu3_pack_frags_kernel, dim3(4 * 8 * 64 / 256), dim3(256), 0, s, w, (bf16x8*)frag_table);
+  const size_t smem = bsed_glu_bwd3n_table_bytes() + 2 * 128 * sizeof(float) + (size_t)4 * 32 * (2 * 32 + 8) * 2;
+  static bool done = false;
+  if (!done) {
+    BSED_HIP(hipFuncSetAttribute((const void*)glu_bwd3n_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+  }
+  hipLaunchKernelGGL(glu_bwd3n_kernel, dim3(G), dim3(G3_THREADS), smem, s, P, (const bf16x8*)frag_table, dlin);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
 }

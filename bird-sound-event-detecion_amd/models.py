@@ -355,6 +355,14 @@ class CRNN(_FlatModule):
                                                           seed)
                 ops.reduce_partials(pdw, G * slabs, 1, co, co, co, co, glu.weight.grad, 0, co, 1)
                 ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
+            elif co == 128 and self.fused_glu_bwd and self.conv_mode == "bf16x3" and self.glu3:
+                # lin recompute + g on the bf16 cores; d_lin goes through HBM to a 1-tap weight-gradient contraction
+                g, dlin, pdb, st2, G = ops.glu_bwd3n(y, blk["scale"], blk["shift"], glu.weight, glu.bias,
+                                                     dpool.contiguous(), B, Hh, Ww, co, (ph, pw), drop_b, 100 + i, seed)
+                ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
+                part, Gw, KP, NP = ops.wgrad(y, dlin, B, Hh, Ww, co, co, a_scale=blk["scale"], a_shift=blk["shift"])
+                ops.reduce_partials(part, Gw, 1, KP, NP, co, co, glu.weight.grad, 0, 1, co)
+                del dlin
             elif co in (32, 64, 128) and self.fused_glu_bwd:
                 # three chained MFMA contractions per tile, y read once, g written once (csrc/glu_bwd.hip)
                 wfwd = ops.pack_weight(glu.weight, 1, co, co, 0, 1, co)

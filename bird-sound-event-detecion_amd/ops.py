@@ -338,6 +338,34 @@ def glu_bwd3(y, scale, shift, w, bias, dpool, B, H, W, C, pool, drop_p, rng_stre
     return g, part_dw, part_db, part_st, G, slabs
 
 
+_frag_tables = {}
+
+
+def glu_bwd3n(y, scale, shift, w, bias, dpool, B, H, W, C, pool, drop_p, rng_stream, seed):
+    """split-fp32 GLU backward for C = 128 without the weight gradient: returns (g, d_lin, part_db, part_st, G)"""
+    ph, pw = pool
+    dev = y.device
+    TH, TW = tile_for(W)
+    ntiles = B * ((H + TH - 1) // TH) * (W // TW)
+    G = int(min(ntiles, 256))
+    tb = _frag_tables.get(str(dev))
+    if tb is None:
+        fn = L.lib().bsed_glu_bwd3n_table_bytes
+        fn.restype = ctypes.c_size_t
+        tb = _frag_tables[str(dev)] = torch.empty(fn(), device=dev, dtype=torch.uint8)
+    g = torch.empty_like(y)
+    dlin = torch.empty_like(y)
+    part_db = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
+    part_st = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
+    _launch(("glu_bwd3n_kernel", 1, C, C, H, W), 2 * 2.0 * B * H * W * C * C,
+            lambda: L.call("bsed_glu_bwd3n", L.ptr(y), L.ptr(scale), L.ptr(shift), _fp(_dp(w)), _fp(_dp(bias)),
+                           L.ptr(dpool), L.ptr(g), L.ptr(dlin), L.ptr(part_db), L.ptr(part_st),
+                           ctypes.c_void_p(tb.data_ptr()), _i(G), _i(B), _i(H), _i(W), _i(C), _i(TH), _i(TW), _i(ph),
+                           _i(pw), ctypes.c_float(drop_p), ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed),
+                           L.stream()))
+    return g, dlin, part_db, part_st, G
+
+
 def bn_finalize(stats, C, count, eps, momentum, gamma, beta, rmean, rvar, nbt):
     dev = stats.device
     mean, invstd, scale, shift = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(4))

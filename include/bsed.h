@@ -220,6 +220,14 @@ int bsed_glu_bwd3(const float* y, const float* scale, const float* shift, const 
                   void* stream);
 int bsed_glu_bwd3_slabs(int C);
 int bsed_glu_bwd3_auto_g(int C);
+/* C = 128 in the split-fp32 mode: g, db and BatchNorm partials as above, but d_lin (NB,H,W,128) is written out and
+ * the Linear weight gradient is a separate 1-tap bsed_wgrad3(in = y with a_scale/a_shift, dy = d_lin).  frag_table:
+ * bsed_glu_bwd3n_table_bytes() of device scratch (filled by the call: both weight operands pre-split). */
+int bsed_glu_bwd3n(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
+                   const float* dpool, float* g, float* dlin, float* part_db, float* part_st, void* frag_table, int G,
+                   int NB, int H, int W, int C, int TH, int TW, int ph, int pw, float drop_p, uint32_t rng_stream,
+                   uint64_t seed, void* stream);
+size_t bsed_glu_bwd3n_table_bytes(void);
 /* Forward of the same stage in the split-fp32 mode, C in {32,64,128}: y (NB,H,W,C) -> pooled (NB,H/ph,W/pw,C);
  * replaces bsed_igemm(BSED_EPI_GLU_POOL) (GLU.forward + nn.Dropout + nn.AvgPool2d, src/models/CNN.py:5-16,59-67).
  * Vertical pooling (ph = 2) is supported for tile widths TW in {2,8,16}. */

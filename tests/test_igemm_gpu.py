@@ -233,3 +233,31 @@ def test_glu_forward_split_fp32_matches_torch(C, B, H, W, pool):
                          e_src=y, e_scale=scale, e_shift=shift, pool=pool, drop_p=0.5, rng_stream=101, seed=5)
     got_d = ops.glu_fwd3(y, scale, shift, w, bias, B, H, W, C, pool, 0.5, 101, 5)
     assert float((got_d - ref_d).abs().max()) < 4e-5 * max(1.0, float(ref_d.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,pool", [(2, 21, 16, (1, 2)), (3, 9, 2, (1, 2)), (1, 313, 8, (1, 2)), (2, 16, 4, (2, 2))])
+def test_glu_backward_c128_split_fp32_matches_fp32_fused_kernel(B, H, W, pool):
+    """bsed_glu_bwd3n (g, d_lin, db, BatchNorm sums) + 1-tap wgrad3 for dW vs csrc/glu_bwd.hip, dropout on"""
+    from bsed_amd import ops
+    C = 128
+    g = torch.Generator().manual_seed(H + W)
+    y = torch.randn(B, H, W, C, generator=g).cuda()
+    scale = (torch.rand(C, generator=g) + 0.5).cuda()
+    shift = (torch.randn(C, generator=g) * 0.3).cuda()
+    w = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+    bias = (torch.randn(C, generator=g) * 0.1).cuda()
+    ph, pw = pool
+    dpool = torch.randn(B, H // ph, W // pw, C, generator=g).cuda()
+    wfwd = ops.pack_weight(w, 1, C, C, 0, 1, C)
+    gr, pdw, pdb, st, G, slabs = ops.glu_bwd_fused(y, scale, shift, wfwd, w, bias, dpool, B, H, W, C, pool, 0.5, 104, 9)
+    dw_ref = torch.zeros(C, C, device="cuda")
+    ops.reduce_partials(pdw, G * slabs, 1, C, C, C, C, dw_ref, 0, C, 1)
+    gq, dlin, pdb2, st2, G2 = ops.glu_bwd3n(y, scale, shift, w, bias, dpool, B, H, W, C, pool, 0.5, 104, 9)
+    part, Gw, KP, NP = ops.wgrad(y, dlin, B, H, W, C, C, a_scale=scale, a_shift=shift, mode="bf16x3")
+    dw = torch.zeros(C, C, device="cuda")
+    ops.reduce_partials(part, Gw, 1, KP, NP, C, C, dw, 0, 1, C)
+    for name, a, b in (("g", gq, gr), ("dW", dw, dw_ref), ("db", pdb2.sum(0)[0], pdb.sum(0)[0]),
+                       ("bn sums", st2.sum(0), st.sum(0))):
+        err = float((a - b).norm() / b.norm())
+        assert err < 3e-5, (name, err)
