@@ -200,37 +200,51 @@ def main():
     roofline = None
     kernels = {}
     if timer is not None:
-        summ = timer.summary()  # {(kernel, taps, CIN, N, H, W): (launches, total_ms, avg_ms, flops_per_launch)}
+        # {(kernel, taps, CIN, N, H, W): (launches, total_ms, avg_ms, flops_per_launch, algorithmic_bytes_per_launch)}
+        summ = timer.summary()
         tot_ms = sum(v[1] for v in summ.values())
         for k in sorted(summ, key=lambda k: -summ[k][1]):
-            c, tms, ams, fl = summ[k]
-            log("  %-52s x%-3d %8.3f ms/step  avg %7.3f ms  %6.1f TFLOP/s" % (
-                "%s t%d CIN%d N%d %dx%d" % k, c // args.steps, tms / args.steps, ams, fl / ams / 1e9))
+            c, tms, ams, fl, nb = summ[k]
+            log("  %-52s x%-3d %8.3f ms/step  avg %7.3f ms  %6.1f TFLOP/s %6.0f GB/s" % (
+                "%s t%d CIN%d N%d %dx%d" % k, c // args.steps, tms / args.steps, ams, fl / ams / 1e9, nb / ams / 1e6))
         # the roofline object is quoted per KERNEL (template instance, the unit rocprofv3 --stats aggregates on):
         # all its launches of the timed region, algorithmic FLOPs = 2 * positions * taps * CIN * N of each launch
         byk = {}
-        for k, (c, tms, ams, fl) in summ.items():
-            a = byk.setdefault(k[0], [0, 0.0, 0.0])
-            a[0] += c; a[1] += tms; a[2] += fl * c
+        for k, (c, tms, ams, fl, nb) in summ.items():
+            a = byk.setdefault(k[0], [0, 0.0, 0.0, 0.0])
+            a[0] += c; a[1] += tms; a[2] += fl * c; a[3] += nb * c
         for name in sorted(byk, key=lambda n: -byk[n][1]):
-            c, tms, fl = byk[name]
-            log("  KERNEL %-34s x%-3d %8.3f ms/step  avg %7.3f ms  %6.1f TFLOP/s" % (
-                name, c // args.steps, tms / args.steps, tms / c, fl / tms / 1e9))
+            c, tms, fl, nb = byk[name]
+            log("  KERNEL %-34s x%-3d %8.3f ms/step  avg %7.3f ms  %6.1f TFLOP/s %6.0f GB/s" % (
+                name, c // args.steps, tms / args.steps, tms / c, fl / tms / 1e9, nb / tms / 1e6))
         name = max(byk, key=lambda n: byk[n][1])
-        launches, total_ms, flops_total = byk[name]
+        launches, total_ms, flops_total, bytes_total = byk[name]
         avg_ms = total_ms / launches
-        achieved = flops_total / (total_ms * 1e-3) / 1e12
-        # kernels named *3_kernel run split-fp32 operands on the bf16 matrix cores: 3 bf16 MFMAs per product, so their
-        # ceiling in algorithmic (fp32-equivalent) FLOP/s is the dense bf16 peak / 3
-        peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if "3_kernel" in name else PEAK_FP32_MFMA_TFLOPS
-        roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
-                    "peak_basis": "dense bf16 MFMA 2500 / 3 (bf16x3 split-fp32 operands)" if "3_kernel" in name
-                    else "fp32 MFMA 157.3 (v_mfma_f32_32x32x2_f32)",
-                    "kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
-                    "algorithmic_gflop_per_launch": round(flops_total / launches / 1e9, 3),
-                    "share_of_mfma_kernel_time": round(total_ms / tot_ms, 3),
-                    "mfma_kernels_ms_per_step": round(tot_ms / args.steps, 3)}
+        tflops = flops_total / (total_ms * 1e-3) / 1e12
+        gbs = bytes_total / (total_ms * 1e-3) / 1e9
+        # kernels named *3_kernel / *3n_kernel run split-fp32 operands on the bf16 matrix cores: 3 bf16 MFMAs per
+        # product, so their ceiling in algorithmic (fp32-equivalent) FLOP/s is the dense bf16 peak / 3
+        split = "3_kernel" in name or "3n_kernel" in name
+        peak_tf = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS
+        # which roof bounds this kernel: its arithmetic intensity against the ridge point of ITS matrix-core ceiling
+        intensity = flops_total / max(bytes_total, 1.0)
+        ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+        basis = ("dense bf16 MFMA 2500 / 3 (bf16x3 split-fp32 operands)" if split
+                 else "fp32 MFMA 157.3 (v_mfma_f32_32x32x2_f32)")
+        common = {"traffic": None, "kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                  "algorithmic_gflop_per_launch": round(flops_total / launches / 1e9, 3),
+                  "algorithmic_mbytes_per_launch": round(bytes_total / launches / 1e6, 2),
+                  "intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
+                  "mfma_tflops": round(tflops, 2), "mfma_peak_tflops": round(peak_tf, 1), "mfma_peak_basis": basis,
+                  "hbm_gbs": round(gbs, 1), "share_of_mfma_kernel_time": round(total_ms / tot_ms, 3),
+                  "mfma_kernels_ms_per_step": round(tot_ms / args.steps, 3)}
+        if intensity >= ridge:
+            roofline = {"bound": "mfma", "achieved": round(tflops, 3), "peak": round(peak_tf, 1), "unit": "TFLOP/s",
+                        "frac": round(tflops / peak_tf, 4)}
+        else:
+            roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(gbs / PEAK_HBM_GBS, 4)}
+        roofline.update(common)
         all_flops = sum(v[0] * v[3] for v in summ.values())
         kernels = {"all_mfma_kernels_tflops": round(all_flops / (tot_ms * 1e-3) / 1e12, 2)}
         # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate

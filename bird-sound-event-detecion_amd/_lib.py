@@ -8,7 +8,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbsed.so")
+LIB_PATH = os.environ.get("BSED_LIB_PATH") or os.path.join(_HERE, "libbsed.so")  # override: A/B experiment builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bsed.h")
 
 _lib = None

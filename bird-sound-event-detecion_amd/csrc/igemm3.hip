@@ -18,6 +18,7 @@
 #define I3_ROW 72  // ushorts per LDS row: 32 hi + 32 lo + 8 pad
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct Igemm3Params {
   BsedIgemmDesc d;
@@ -31,8 +32,15 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((uint32_t)h << 16); }
 __device__ __forceinline__ int crow3(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
-template <int BN, int STATS>
-__global__ __launch_bounds__(I3_THREADS) void igemm3_kernel(const Igemm3Params P) {
+// RB = 32-row blocks per wave: 1 -> a workgroup covers 128 positions, 2 -> 256 (TH*TW = 256).  With RB = 2 every B
+// fragment read from LDS feeds two MFMA row blocks: 24 ds_read_b128 per 48 MFMAs instead of 20 per 24 -- the LDS pipe
+// (one per CU, shared by all resident waves) was the co-limiter of the RB = 1 kernel at ~30 % of the MFMA peak -- and a
+// weight slab is staged once per 256 positions instead of once per 128.
+template <int BN, int STATS, int RB, int PV>
+// (waves_per_eu caps the register budget the allocator aims for: without it the prefetch registers were spilled to
+// scratch right after their loads, which serialised the loads again)
+__global__ __launch_bounds__(I3_THREADS) __attribute__((amdgpu_waves_per_eu(1, RB == 2 ? 2 : 3)))
+void igemm3_kernel(const Igemm3Params P) {
   constexpr int NT = BN / 32;
   const BsedIgemmDesc& p = P.d;
   extern __shared__ __align__(16) unsigned short smem3[];
@@ -46,76 +54,118 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3_kernel(const Igemm3Params P
   const int th0 = th_i * p.TH, tw0 = tw_i * p.TW;
   const int n0 = blockIdx.y * BN;
   const int PW = P.PW;
-  const int m = wave * 32 + li;
-  const int abase = (((m >> P.lgTW) + p.hh) * PW + (m & (p.TW - 1)) + p.hw) * I3_ROW + 8 * lh;
+  int abase[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int m = (wave * RB + rb) * 32 + li;
+    abase[rb] = (((m >> P.lgTW) + p.hh) * PW + (m & (p.TW - 1)) + p.hw) * I3_ROW + 8 * lh;
+  }
 
-  f32x16 acc[NT];
+  f32x16 acc[RB][NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][j][r] = 0.f;
 
   const float* inb = p.in + (size_t)nb * p.H * p.W * p.in_pitch;
   const int nchunks = p.CIN / I3_KC;
+  // Activation patch of one 32-channel chunk: PV float4 per thread.  The patch of chunk c+1 is fetched into REGISTERS
+  // during the taps of chunk c (its HBM latency was ~1/3 of the kernel time when exposed at every chunk boundary) and
+  // split into bf16 hi / lo when it is written to LDS.  Element e = tid + u*256 -> (position e/8, channels 4*(e%8)..).
+  const int a_total = P.PP * (I3_KC / 4);
+  f32x4 pv[PV];
+  int poff[PV];  // element offset of this thread's u-th float4 inside the image (channel chunk 0), -1 = zero padding
+#pragma unroll
+  for (int u = 0; u < PV; ++u) {
+    const int e = tid + u * I3_THREADS;
+    const int c4 = e & 7, pos = e >> 3;
+    const int pr = (pos * P.pw_magic) >> 20, pc = pos - pr * PW;
+    const int gh = th0 - p.hh + pr, gw = tw0 - p.hw + pc;
+    poff[u] = (e < a_total && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) ? (gh * p.W + gw) * p.in_pitch + 4 * c4 : -1;
+  }
+#pragma unroll
+  for (int u = 0; u < PV; ++u)
+    pv[u] = poff[u] >= 0 ? *reinterpret_cast<const f32x4*>(inb + poff[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
   for (int ch = 0; ch < nchunks; ++ch) {
-    const int c0 = ch * I3_KC;
-    __syncthreads();
-    // activation patch: fp32 from HBM, split into bf16 hi / lo while staging
-    const int a_total = P.PP * (I3_KC / 4);
-    for (int e0 = tid; e0 < a_total; e0 += 4 * I3_THREADS) {
-      float4 v[4];
+    __syncthreads();  // every wave is done with the previous chunk's patch and slab
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = e0 + u * I3_THREADS;
-        const int c4 = e % (I3_KC / 4), pos = e / (I3_KC / 4);
-        const int pr = (pos * P.pw_magic) >> 20, pc = pos - pr * PW;
-        const int gh = th0 - p.hh + pr, gw = tw0 - p.hw + pc;
-        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e < a_total && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W)
-          v[u] = *reinterpret_cast<const float4*>(inb + ((size_t)gh * p.W + gw) * p.in_pitch + c0 + 4 * c4);
-      }
+    for (int u = 0; u < PV; ++u) {
+      const int e = tid + u * I3_THREADS;
+      if (e < a_total) {
+        unsigned short hi[4], lo[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = e0 + u * I3_THREADS;
-        if (e < a_total) {
-          const int c4 = e % (I3_KC / 4), pos = e / (I3_KC / 4);
-          const float f[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-          unsigned short hi[4], lo[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            hi[i] = f2bf(f[i]);
-            lo[i] = f2bf(f[i] - bf2f(hi[i]));
-          }
-          unsigned short* dst = As + pos * I3_ROW + 4 * c4;
-          *reinterpret_cast<uint2*>(dst) = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
-          *reinterpret_cast<uint2*>(dst + 32) = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+        for (int i = 0; i < 4; ++i) {
+          hi[i] = f2bf(pv[u][i]);
+          lo[i] = f2bf(pv[u][i] - bf2f(hi[i]));
         }
+        unsigned short* dst = As + (e >> 3) * I3_ROW + 4 * (e & 7);
+        *reinterpret_cast<uint2*>(dst) = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
+        *reinterpret_cast<uint2*>(dst + 32) = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
       }
     }
+    // weight slab [BN][64] bf16 (hi | lo), pre-split: 128 B per output channel, NT uint4 per thread.  The slab of tap
+    // t+1 is fetched into REGISTERS before the MFMAs of tap t and written to the (single) LDS buffer after the next
+    // barrier, so its L2 latency hides behind 24 MFMAs per wave without costing LDS (three workgroups stay resident).
+    u32x4 pre[NT];  // (a native vector type: HIP's uint4 struct array was left in scratch memory)
+    // this thread's NT uint4 of a slab sit at a fixed offset from the slab base (8 uint4 = 128 B per output channel)
+    const u32x4* wthr = reinterpret_cast<const u32x4*>(p.w) + ((size_t)ch * p.NP + n0) * 8 + tid;
+    const size_t tap_stride = (size_t)nchunks * p.NP * 8;  // uint4 per tap
+#pragma unroll
+    for (int u = 0; u < NT; ++u) pre[u] = wthr[u * I3_THREADS];
     for (int tap = 0; tap < p.ntaps; ++tap) {
-      if (tap > 0) __syncthreads();
-      // weight slab [BN][64] bf16 (hi | lo), pre-split: 128 B per output channel
-      const unsigned short* wsrc = reinterpret_cast<const unsigned short*>(p.w) +
-                                   (((size_t)tap * nchunks + ch) * p.NP + n0) * 64;
-      for (int e = tid; e < BN * 8; e += I3_THREADS) {
-        const int n = e >> 3, part = e & 7;
-        *reinterpret_cast<uint4*>(Bs + n * I3_ROW + part * 8) = *reinterpret_cast<const uint4*>(wsrc + (size_t)n * 64 + part * 8);
+      if (tap > 0) __syncthreads();  // every wave is done reading the previous slab
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const int e = tid + u * I3_THREADS;
+        *reinterpret_cast<u32x4*>(Bs + (e >> 3) * I3_ROW + (e & 7) * 8) = pre[u];
       }
       __syncthreads();
-      const unsigned short* arow = As + abase + (p.dh[tap] * PW + p.dw[tap]) * I3_ROW;
-      const unsigned short* brow = Bs + li * I3_ROW + 8 * lh;
+      if (tap == 0 && ch + 1 < nchunks) {  // next chunk's patch: in flight during this chunk's taps
 #pragma unroll
-      for (int k0 = 0; k0 < I3_KC; k0 += 16) {
-        const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(arow + k0);
-        const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(arow + 32 + k0);
+        for (int u = 0; u < PV; ++u)
+          pv[u] = poff[u] >= 0 ? *reinterpret_cast<const f32x4*>(inb + poff[u] + (ch + 1) * I3_KC) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      {  // next tap's slab (the last tap re-reads its own: no branch around the loads)
+        const u32x4* wn = wthr + (size_t)min(tap + 1, p.ntaps - 1) * tap_stride;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) pre[u] = wn[u * I3_THREADS];
+      }
+      const int toff = (p.dh[tap] * PW + p.dw[tap]) * I3_ROW;
+      const unsigned short* brow = Bs + li * I3_ROW + 8 * lh;
+      // every operand fragment of the tap is fetched from LDS first (20 ds_read_b128 at RB = 1), then the 24 * RB
+      // MFMAs run back to back: one LDS wait per tap instead of one per accumulator tile (PMC: the waves of the
+      // read-then-multiply loop were parked 50 % of their cycles with the MFMA pipe 31 % busy)
+      bf16x8 a_hi[2][RB], a_lo[2][RB], b_hi[2][NT], b_lo[2][NT];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          a_hi[kk][rb] = *reinterpret_cast<const bf16x8*>(As + abase[rb] + toff + 16 * kk);
+          a_lo[kk][rb] = *reinterpret_cast<const bf16x8*>(As + abase[rb] + toff + 32 + 16 * kk);
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const bf16x8 b_hi = *reinterpret_cast<const bf16x8*>(brow + 32 * j * I3_ROW + k0);
-          const bf16x8 b_lo = *reinterpret_cast<const bf16x8*>(brow + 32 * j * I3_ROW + 32 + k0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[j], 0, 0, 0);
+          b_hi[kk][j] = *reinterpret_cast<const bf16x8*>(brow + 32 * j * I3_ROW + 16 * kk);
+          b_lo[kk][j] = *reinterpret_cast<const bf16x8*>(brow + 32 * j * I3_ROW + 32 + 16 * kk);
         }
+      }
+      // independent accumulators are interleaved so that consecutive MFMAs never depend on each other
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[rb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[kk][rb], b_hi[kk][j], acc[rb][j], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[rb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[kk][rb], b_lo[kk][j], acc[rb][j], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[rb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[kk][rb], b_hi[kk][j], acc[rb][j], 0, 0, 0);
       }
     }
   }
@@ -132,20 +182,22 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3_kernel(const Igemm3Params P
   }
   const int nbase = n0 + li;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int mm = wave * 32 + crow3(r, lh);
-    const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
-    const bool pok = gh < p.H && gw < p.W;
-    float* orow = p.out + (((size_t)nb * p.H + gh) * p.W + gw) * p.out_pitch + nbase;
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      if (pok && nok[j]) {
-        const float v = acc[j][r] + bias[j];
-        orow[32 * j] = v;
-        if (STATS) { s0[j] += v; s1[j] = fmaf(v, v, s1[j]); }
+    for (int r = 0; r < 16; ++r) {
+      const int mm = (wave * RB + rb) * 32 + crow3(r, lh);
+      const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
+      const bool pok = gh < p.H && gw < p.W;
+      float* orow = p.out + (((size_t)nb * p.H + gh) * p.W + gw) * p.out_pitch + nbase;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (pok && nok[j]) {
+          const float v = acc[rb][j][r] + bias[j];
+          orow[32 * j] = v;
+          if (STATS) { s0[j] += v; s1[j] = fmaf(v, v, s1[j]); }
+        }
       }
     }
-  }
   if (STATS) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem3);  // [4][2][BN]
@@ -230,16 +282,28 @@ extern "C" int bsed_pack_weight3(const float* src, void* dst, int ntaps, int K, 
   return BSED_OK;
 }
 
-template <int BN, int STATS>
-static int launch_i3(const Igemm3Params& P, dim3 grid, size_t smem, hipStream_t s) {
+template <int BN, int STATS, int RB, int PV>
+static int launch_i3pv(const Igemm3Params& P, dim3 grid, size_t smem, hipStream_t s) {
   static bool done = false;
   if (!done) {
-    BSED_HIP(hipFuncSetAttribute((const void*)igemm3_kernel<BN, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    BSED_HIP(hipFuncSetAttribute((const void*)igemm3_kernel<BN, STATS, RB, PV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
-  hipLaunchKernelGGL((igemm3_kernel<BN, STATS>), grid, dim3(I3_THREADS), smem, s, P);
+  hipLaunchKernelGGL((igemm3_kernel<BN, STATS, RB, PV>), grid, dim3(I3_THREADS), smem, s, P);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
+}
+
+// PV = float4 patch elements per thread: ceil(PP * 8 / 256), instantiated for 6 (up to 192 patch positions: the 18x10
+// patch of a 16x8 tile), 9 (288: tall narrow tiles) and 12 (384: the 256-position tiles)
+template <int BN, int STATS, int RB>
+static int launch_i3(const Igemm3Params& P, dim3 grid, size_t smem, hipStream_t s) {
+  const int need = ceil_div(P.PP * 8, I3_THREADS);
+  if (RB == 1 && need <= 6) return launch_i3pv<BN, STATS, RB, 6>(P, grid, smem, s);
+  if (RB == 1 && need <= 9) return launch_i3pv<BN, STATS, RB, 9>(P, grid, smem, s);
+  if (need <= 12) return launch_i3pv<BN, STATS, RB, 12>(P, grid, smem, s);
+  bsed_set_error("bsed_igemm3: patch of %d positions exceeds the 384 supported", P.PP);
+  return BSED_ERR_ARG;
 }
 
 extern "C" int bsed_igemm3(const BsedIgemmDesc* desc, void* stream) {
@@ -251,7 +315,9 @@ extern "C" int bsed_igemm3(const BsedIgemmDesc* desc, void* stream) {
   BSED_CHECK_ARG(d.epilogue == BSED_EPI_PLAIN || d.epilogue == BSED_EPI_STATS, "bsed_igemm3: PLAIN / STATS epilogues only");
   BSED_CHECK_ARG(d.epilogue != BSED_EPI_STATS || d.stats, "bsed_igemm3: STATS needs a stats buffer");
   BSED_CHECK_ARG(d.NB > 0 && d.H > 0 && d.W > 0 && d.CIN > 0 && d.CIN % 32 == 0 && d.N > 0, "bsed_igemm3: CIN must be a multiple of 32");
-  BSED_CHECK_ARG(d.TH * d.TW == I3_M && d.W % d.TW == 0, "bsed_igemm3: TH*TW must be 128 and TW divide W");
+  BSED_CHECK_ARG((d.TH * d.TW == I3_M || d.TH * d.TW == 2 * I3_M) && d.W % d.TW == 0,
+                 "bsed_igemm3: TH*TW must be 128 or 256 (N a multiple of 128 only) and TW divide W");
+  const int RB = d.TH * d.TW / I3_M;
   P.lgTW = 0;
   while ((1 << P.lgTW) < d.TW) ++P.lgTW;
   BSED_CHECK_ARG((1 << P.lgTW) == d.TW, "bsed_igemm3: TW must be a power of two");
@@ -261,6 +327,7 @@ extern "C" int bsed_igemm3(const BsedIgemmDesc* desc, void* stream) {
   BSED_CHECK_ARG(d.in_pitch >= d.CIN && d.in_pitch % 4 == 0 && d.out_pitch >= d.N, "bsed_igemm3: bad pitch");
   BSED_CHECK_ARG(d.NP % 32 == 0 && d.NP >= d.N, "bsed_igemm3: NP must be N rounded up to 32");
   const int BN = d.NP % 128 == 0 ? 128 : (d.NP % 64 == 0 ? 64 : 32);
+  BSED_CHECK_ARG(RB == 1 || BN == 128, "bsed_igemm3: 256-position tiles are built for N a multiple of 128");
   d.tilesH = ceil_div(d.H, d.TH);
   d.tilesW = d.W / d.TW;
   P.PW = d.TW + 2 * d.hw;
@@ -278,7 +345,8 @@ extern "C" int bsed_igemm3(const BsedIgemmDesc* desc, void* stream) {
   dim3 grid((unsigned)ntiles, d.NP / BN);
   hipStream_t s = (hipStream_t)stream;
   const bool st = d.epilogue == BSED_EPI_STATS;
-  if (BN == 128) return st ? launch_i3<128, 1>(P, grid, bytes, s) : launch_i3<128, 0>(P, grid, bytes, s);
-  if (BN == 64) return st ? launch_i3<64, 1>(P, grid, bytes, s) : launch_i3<64, 0>(P, grid, bytes, s);
-  return st ? launch_i3<32, 1>(P, grid, bytes, s) : launch_i3<32, 0>(P, grid, bytes, s);
+  if (BN == 128 && RB == 2) return st ? launch_i3<128, 1, 2>(P, grid, bytes, s) : launch_i3<128, 0, 2>(P, grid, bytes, s);
+  if (BN == 128) return st ? launch_i3<128, 1, 1>(P, grid, bytes, s) : launch_i3<128, 0, 1>(P, grid, bytes, s);
+  if (BN == 64) return st ? launch_i3<64, 1, 1>(P, grid, bytes, s) : launch_i3<64, 0, 1>(P, grid, bytes, s);
+  return st ? launch_i3<32, 1, 1>(P, grid, bytes, s) : launch_i3<32, 0, 1>(P, grid, bytes, s);
 }

@@ -47,22 +47,22 @@ class KernelTimer:
     recorded on the stream the kernels are launched on (torch's current stream)."""
 
     def __init__(self):
-        self.records = {}  # key -> [flops_per_launch, [(start, end), ...]]
+        self.records = {}  # key -> [flops_per_launch, [(start, end), ...], algorithmic_bytes_per_launch]
 
-    def launch(self, key, flops, fn):
+    def launch(self, key, flops, fn, nbytes):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
-        rec = self.records.setdefault(key, [flops, []])
+        rec = self.records.setdefault(key, [flops, [], nbytes])
         rec[1].append((s, e))
 
     def summary(self):
-        """{key: (launches, total_ms, avg_ms, flops_per_launch)} -- call after a device sync"""
+        """{key: (launches, total_ms, avg_ms, flops_per_launch, bytes_per_launch)} -- call after a device sync"""
         out = {}
-        for key, (flops, evs) in self.records.items():
+        for key, (flops, evs, nbytes) in self.records.items():
             ms = [s.elapsed_time(e) for s, e in evs]
-            out[key] = (len(ms), float(sum(ms)), float(sum(ms) / len(ms)), flops)
+            out[key] = (len(ms), float(sum(ms)), float(sum(ms) / len(ms)), flops, nbytes)
         return out
 
 
@@ -74,11 +74,17 @@ def set_timer(t):
     _timer = t
 
 
-def _launch(key, flops, fn):
+def _launch(key, flops, fn, nbytes=None):
+    """key = (kernel, taps, CIN, N, H, W).  nbytes = ALGORITHMIC HBM bytes of the launch (each activation tensor the
+    op must read or write, once; weights and partial slabs not counted); default: a (positions, CIN) input and a
+    (positions, N) output in fp32, positions recovered from the FLOP count."""
     if _timer is None:
         fn()
     else:
-        _timer.launch(key, flops, fn)
+        if nbytes is None:
+            _, taps, cin, n, _, _ = key
+            nbytes = 4.0 * (flops / (2.0 * taps * cin * n)) * (cin + n)
+        _timer.launch(key, flops, fn, nbytes)
 
 
 def round_up(v, m):
@@ -146,6 +152,9 @@ def igemm(inp, wpk, N, NB, H, W, CIN, taps=((0, 0),), bias=None, out=None, epilo
     return out, stats
 
 
+IGEMM3_RB = {"rb": 1}  # 2 = 256-position tiles where they fit (measured no faster than 1: kept for A-B measurements)
+
+
 def pack_weight3(src, ntaps, K, N, s_tap, s_k, s_n):
     """bf16 hi/lo split weights for igemm3: uint16 (ntaps, K/32, NP, 64)"""
     NP = round_up(N, 32)
@@ -160,6 +169,12 @@ def igemm3(inp, w3, N, NB, H, W, CIN, taps, bias=None, epilogue=EPI_PLAIN):
     d = IgemmDesc()
     TH, TW = tile_for(W)
     NP = w3.shape[2]
+    bn = 128 if NP % 128 == 0 else (64 if NP % 64 == 0 else 32)
+    # 256-position tiles (two row blocks per wave: half the LDS reads and weight-slab stagings per MFMA) when they
+    # still fill the chip: 128 output channels per workgroup and at least ~4 workgroups per CU
+    rb = 2 if (IGEMM3_RB["rb"] == 2 and bn == 128 and H >= 2 * TH and (2 * TH + 2) * (TW + 2) <= 384 and
+               NB * ((H + 2 * TH - 1) // (2 * TH)) * (W // TW) * (NP // 128) >= 1024) else 1
+    TH *= rb
     dev = inp.device
     out = torch.empty((NB, H, W, N), device=dev, dtype=torch.float32)
     ntiles = NB * ((H + TH - 1) // TH) * (W // TW)
@@ -174,8 +189,7 @@ def igemm3(inp, w3, N, NB, H, W, CIN, taps, bias=None, epilogue=EPI_PLAIN):
         d.dh[i], d.dw[i] = a, b
     d.ph = d.pw = 1; d.Hp, d.Wp = H, W
     d.epilogue = epilogue
-    bn = 128 if NP % 128 == 0 else (64 if NP % 64 == 0 else 32)
-    _launch((f"igemm3_kernel<{bn}, {1 if epilogue == EPI_STATS else 0}>", len(taps), CIN, N, H, W),
+    _launch((f"igemm3_kernel<{bn}, {1 if epilogue == EPI_STATS else 0}, {rb}>", len(taps), CIN, N, H, W),
             2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call("bsed_igemm3", ctypes.byref(d), L.stream()))
     return out, stats
 
@@ -290,11 +304,12 @@ def glu_bwd_fused(y, scale, shift, wfwd, w, bias, dpool, B, H, W, C, pool, drop_
     part_db = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
     part_st = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
     flops = 3 * 2.0 * B * H * W * C * C
+    nbytes = 4.0 * B * H * W * C * (2.0 + 1.0 / (ph * pw))  # y, g, d_pooled
     _launch((f"glu_bwd_fused_kernel<{C}, {8 if C == 128 else 4}>", 1, C, C, H, W), flops,
             lambda: L.call("bsed_glu_bwd_fused", L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(wfwd), _fp(_dp(w)),
                            _fp(_dp(bias)), L.ptr(dpool), L.ptr(g), L.ptr(part_dw), L.ptr(part_db), L.ptr(part_st),
                            _i(G), _i(B), _i(H), _i(W), _i(C), _i(TH), _i(TW), _i(ph), _i(pw), ctypes.c_float(drop_p),
-                           ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream()))
+                           ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream()), nbytes)
     return g, part_dw, part_db, part_st, G, slabs
 
 
@@ -313,7 +328,8 @@ def glu_fwd3(y, scale, shift, w, bias, B, H, W, C, pool, drop_p, rng_stream, see
     _launch((f"glu_fwd3_kernel<{C}>", 1, C, C, H, W), 2.0 * B * H * W * C * C,
             lambda: L.call("bsed_glu_fwd3", L.ptr(y), L.ptr(scale), L.ptr(shift), _fp(_dp(w)), _fp(_dp(bias)),
                            L.ptr(out), _i(G), _i(B), _i(H), _i(W), _i(C), _i(TH), _i(TW), _i(ph), _i(pw),
-                           ctypes.c_float(drop_p), ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream()))
+                           ctypes.c_float(drop_p), ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream()),
+            4.0 * B * H * W * C * (1.0 + 1.0 / (ph * pw)))  # y, pooled
     return out
 
 
@@ -334,7 +350,8 @@ def glu_bwd3(y, scale, shift, w, bias, dpool, B, H, W, C, pool, drop_p, rng_stre
             lambda: L.call("bsed_glu_bwd3", L.ptr(y), L.ptr(scale), L.ptr(shift), _fp(_dp(w)), _fp(_dp(bias)),
                            L.ptr(dpool), L.ptr(g), L.ptr(part_dw), L.ptr(part_db), L.ptr(part_st), _i(G), _i(B), _i(H),
                            _i(W), _i(C), _i(TH), _i(TW), _i(ph), _i(pw), ctypes.c_float(drop_p),
-                           ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream()))
+                           ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream()),
+            4.0 * B * H * W * C * (2.0 + 1.0 / (ph * pw)))  # y, g, d_pooled
     return g, part_dw, part_db, part_st, G, slabs
 
 
@@ -362,7 +379,8 @@ def glu_bwd3n(y, scale, shift, w, bias, dpool, B, H, W, C, pool, drop_p, rng_str
                            L.ptr(dpool), L.ptr(g), L.ptr(dlin), L.ptr(part_db), L.ptr(part_st),
                            ctypes.c_void_p(tb.data_ptr()), _i(G), _i(B), _i(H), _i(W), _i(C), _i(TH), _i(TW), _i(ph),
                            _i(pw), ctypes.c_float(drop_p), ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed),
-                           L.stream()))
+                           L.stream()),
+            4.0 * B * H * W * C * (3.0 + 1.0 / (ph * pw)))  # y, g, d_lin, d_pooled
     return g, dlin, part_db, part_st, G
 
 

@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bsed_amd import ops  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "wgrad9"
+if os.environ.get("BSED_IGEMM3_RB"):
+    ops.IGEMM3_RB["rb"] = int(os.environ["BSED_IGEMM3_RB"])
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 B, H, W, C = 256, 216, 8, 128
 dev = "cuda"
@@ -23,6 +25,9 @@ def run():
     if which == "conv":
         wpk = ops.pack_weight(w, 9, C, C, 1, 9, C * 9)
         return ops.igemm(x, wpk, C, B, H, W, C, taps=ops.TAPS3x3, epilogue=ops.EPI_STATS)
+    if which == "conv3":  # split-fp32 3x3 conv forward + BN partial sums (igemm3), the layer-4 shape
+        w3 = ops.pack_weight3(w, 9, C, C, 1, 9, C * 9)
+        return ops.igemm3(x, w3, C, B, H, W, C, ops.TAPS3x3, epilogue=ops.EPI_STATS)
     if which == "wgrad1":
         return ops.wgrad(x, dy, 1, B * H * W, 1, C, C)
     raise SystemExit("unknown kernel")
@@ -37,5 +42,5 @@ for _ in range(reps):
 e.record()
 torch.cuda.synchronize()
 ms = s.elapsed_time(e) / reps
-flops = 2.0 * B * H * W * C * C * (9 if which in ("wgrad9", "conv") else 1)
+flops = 2.0 * B * H * W * C * C * (9 if which in ("wgrad9", "conv", "conv3") else 1)
 print(f"{which}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s")
