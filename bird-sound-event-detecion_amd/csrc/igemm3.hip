@@ -282,6 +282,147 @@ extern "C" int bsed_pack_weight3(const float* src, void* dst, int ntaps, int K, 
   return BSED_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// CIN = 16 (the second convolution of the network, 16 -> 32 channels on the 432 x 64 map): one MFMA K step per tap.
+// With 3 MFMAs per tap the two-barriers-per-tap pipeline above is all overhead, so this variant keeps the pre-split
+// weights of ALL taps in LDS (fragment order, 18 KB per 32 output channels, loaded once per persistent workgroup) and
+// only the activation patch moves per tile: [prefetched registers -> LDS] -> barrier -> 27 MFMAs per wave -> epilogue.
+// BatchNorm partial sums accumulate in registers over the tiles of a workgroup (one partial row per workgroup).
+#define I3S_ROW 40  // ushorts per patch row: 16 hi | 16 lo | 8 pad (80 B = 5 x 16 B)
+
+__global__ void pack_weight3s_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int ntaps, int N,
+                                     int NP, long s_tap, long s_k, long s_n) {
+  // table[jn][tap][hi|lo][lane][8]: lane (li, lh) holds k = 8*lh + q of output channel n = 32*jn + li
+  const long total = (long)(NP / 32) * ntaps * 64;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(e & 63), li = lane & 31, lh = lane >> 5;
+    const int tap = (int)((e >> 6) % ntaps), jn = (int)((e >> 6) / ntaps);
+    const int n = 32 * jn + li;
+    unsigned short* d = dst + ((((long)jn * ntaps + tap) * 2) * 64 + lane) * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float v = n < N ? src[tap * s_tap + (long)(8 * lh + q) * s_k + n * s_n] : 0.f;
+      const unsigned short hi = f2bf(v);
+      d[q] = hi;
+      d[64 * 8 + q] = f2bf(v - bf2f(hi));
+    }
+  }
+}
+
+template <int STATS, int NTAPS>
+__global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params P) {
+  constexpr int PV = 4;  // float4 patch elements per thread: up to 256 patch positions x 4
+  const BsedIgemmDesc& p = P.d;
+  extern __shared__ __align__(16) unsigned short smem3[];
+  u32x4* Wf = reinterpret_cast<u32x4*>(smem3);               // [NTAPS][2][64]
+  unsigned short* As = smem3 + NTAPS * 2 * 64 * 8;           // [PP][40]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int jn = blockIdx.y, n0 = 32 * jn;
+  const int PW = P.PW;
+  for (int i = tid; i < NTAPS * 2 * 64; i += I3_THREADS)
+    Wf[i] = reinterpret_cast<const u32x4*>(p.w)[(size_t)jn * NTAPS * 2 * 64 + i];
+  const int m = wave * 32 + li;
+  const int abase = (((m >> P.lgTW) + p.hh) * PW + (m & (p.TW - 1)) + p.hw) * I3S_ROW + 8 * lh;
+  int toff[NTAPS];
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t) toff[t] = (p.dh[t] * PW + p.dw[t]) * I3S_ROW;
+  const int n = n0 + li;
+  const bool nok = n < p.N;
+  const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+  float s0 = 0.f, s1 = 0.f;
+  const int a_total = P.PP * 4;
+  const int ntiles = p.NB * p.tilesH * p.tilesW;
+
+  // patch element e = tid + u*256 -> (position e/4, channels 4*(e%4)..): tile-independent part of the address
+  int ppr[PV], ppc[PV];
+#pragma unroll
+  for (int u = 0; u < PV; ++u) {
+    const int e = tid + u * I3_THREADS, pos = e >> 2;
+    ppr[u] = (pos * P.pw_magic) >> 20;
+    ppc[u] = pos - ppr[u] * PW;
+  }
+  f32x4 pv[PV];
+  auto issue = [&](int tile) {
+    const int tw_i = tile % p.tilesW; const int r1 = tile / p.tilesW;
+    const int th_i = r1 % p.tilesH, nb = r1 / p.tilesH;
+    const float* inb = p.in + (size_t)nb * p.H * p.W * p.in_pitch;
+#pragma unroll
+    for (int u = 0; u < PV; ++u) {
+      const int e = tid + u * I3_THREADS;
+      const int gh = th_i * p.TH - p.hh + ppr[u], gw = tw_i * p.TW - p.hw + ppc[u];
+      const bool ok = e < a_total && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+      pv[u] = ok ? *reinterpret_cast<const f32x4*>(inb + ((size_t)gh * p.W + gw) * p.in_pitch + 4 * (e & 3))
+                 : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  if ((int)blockIdx.x < ntiles) issue(blockIdx.x);
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tw_i = tile % p.tilesW; const int r1 = tile / p.tilesW;
+    const int th_i = r1 % p.tilesH, nb = r1 / p.tilesH;
+    const int th0 = th_i * p.TH, tw0 = tw_i * p.TW;
+    __syncthreads();  // every wave is done reading the previous patch (and, first time, Wf is complete)
+#pragma unroll
+    for (int u = 0; u < PV; ++u) {
+      const int e = tid + u * I3_THREADS;
+      if (e < a_total) {
+        unsigned short hi[4], lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          hi[i] = f2bf(pv[u][i]);
+          lo[i] = f2bf(pv[u][i] - bf2f(hi[i]));
+        }
+        unsigned short* dst = As + (e >> 2) * I3S_ROW + 4 * (e & 3);
+        *reinterpret_cast<uint2*>(dst) = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
+        *reinterpret_cast<uint2*>(dst + 16) = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);  // next tile's patch: in flight during the MFMAs
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    bf16x8 a_hi[NTAPS], a_lo[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+      a_hi[t] = *reinterpret_cast<const bf16x8*>(As + abase + toff[t]);
+      a_lo[t] = *reinterpret_cast<const bf16x8*>(As + abase + toff[t] + 16);
+    }
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+      const bf16x8 b_hi = __builtin_bit_cast(bf16x8, Wf[(t * 2 + 0) * 64 + lane]);
+      const bf16x8 b_lo = __builtin_bit_cast(bf16x8, Wf[(t * 2 + 1) * 64 + lane]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[t], b_hi, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[t], b_lo, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[t], b_hi, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mm = wave * 32 + crow3(r, lh);
+      const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
+      if (gh < p.H && nok) {
+        const float v = acc[r] + bias;
+        p.out[(((size_t)nb * p.H + gh) * p.W + gw) * p.out_pitch + n] = v;
+        if (STATS) { s0 += v; s1 = fmaf(v, v, s1); }
+      }
+    }
+  }
+  if (STATS) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(As);  // [4 waves][2][32]
+    const float a = s0 + __shfl_xor(s0, 32, 64), b = s1 + __shfl_xor(s1, 32, 64);
+    if (lh == 0) { red[(wave * 2 + 0) * 32 + li] = a; red[(wave * 2 + 1) * 32 + li] = b; }
+    __syncthreads();
+    if (tid < 64) {
+      const int which = tid >> 5, c = tid & 31;
+      if (n0 + c < p.N)
+        p.stats[((size_t)blockIdx.x * 2 + which) * p.N + n0 + c] =
+            red[(0 * 2 + which) * 32 + c] + red[(1 * 2 + which) * 32 + c] + red[(2 * 2 + which) * 32 + c] + red[(3 * 2 + which) * 32 + c];
+    }
+  }
+}
+
 template <int BN, int STATS, int RB, int PV>
 static int launch_i3pv(const Igemm3Params& P, dim3 grid, size_t smem, hipStream_t s) {
   static bool done = false;
@@ -349,4 +490,63 @@ extern "C" int bsed_igemm3(const BsedIgemmDesc* desc, void* stream) {
   if (BN == 128) return st ? launch_i3<128, 1, 1>(P, grid, bytes, s) : launch_i3<128, 0, 1>(P, grid, bytes, s);
   if (BN == 64) return st ? launch_i3<64, 1, 1>(P, grid, bytes, s) : launch_i3<64, 0, 1>(P, grid, bytes, s);
   return st ? launch_i3<32, 1, 1>(P, grid, bytes, s) : launch_i3<32, 0, 1>(P, grid, bytes, s);
+}
+
+// ---- CIN = 16 variant: w = bsed_pack_weight3s table; persistent grid of G workgroups per 32 output channels;
+// stats (STATS epilogue) has G rows (one per workgroup), not one per tile
+extern "C" int bsed_pack_weight3s(const float* src, void* dst, int ntaps, int N, int NP, long s_tap, long s_k, long s_n,
+                                  void* stream) {
+  BSED_CHECK_ARG(src && dst && ntaps > 0 && N > 0 && NP >= N && NP % 32 == 0, "bsed_pack_weight3s: bad argument");
+  const long total = (long)(NP / 32) * ntaps * 64;
+  hipLaunchKernelGGL(pack_weight3s_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     (unsigned short*)dst, ntaps, N, NP, s_tap, s_k, s_n);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_igemm3s_auto_g(void) { return 1024; }
+
+extern "C" int bsed_igemm3s(const BsedIgemmDesc* desc, int G, void* stream) {
+  BSED_CHECK_ARG(desc, "bsed_igemm3s: null descriptor");
+  Igemm3Params P;
+  P.d = *desc;
+  BsedIgemmDesc& d = P.d;
+  BSED_CHECK_ARG(d.in && d.w && d.out, "bsed_igemm3s: null tensor");
+  BSED_CHECK_ARG(d.epilogue == BSED_EPI_PLAIN || d.epilogue == BSED_EPI_STATS, "bsed_igemm3s: PLAIN / STATS epilogues only");
+  BSED_CHECK_ARG(d.epilogue != BSED_EPI_STATS || d.stats, "bsed_igemm3s: STATS needs a stats buffer");
+  BSED_CHECK_ARG(d.NB > 0 && d.H > 0 && d.W > 0 && d.CIN == 16 && d.N > 0, "bsed_igemm3s: built for CIN = 16");
+  BSED_CHECK_ARG(d.TH * d.TW == I3_M && d.W % d.TW == 0, "bsed_igemm3s: TH*TW must be 128 and TW divide W");
+  P.lgTW = 0;
+  while ((1 << P.lgTW) < d.TW) ++P.lgTW;
+  BSED_CHECK_ARG((1 << P.lgTW) == d.TW, "bsed_igemm3s: TW must be a power of two");
+  BSED_CHECK_ARG(d.ntaps == 9 || d.ntaps == 1, "bsed_igemm3s: 9 or 1 taps");
+  for (int t = 0; t < d.ntaps; ++t)
+    BSED_CHECK_ARG(abs(d.dh[t]) <= d.hh && abs(d.dw[t]) <= d.hw, "bsed_igemm3s: tap %d outside the halo", t);
+  BSED_CHECK_ARG(d.in_pitch >= d.CIN && d.in_pitch % 4 == 0 && d.out_pitch >= d.N, "bsed_igemm3s: bad pitch");
+  BSED_CHECK_ARG(d.NP % 32 == 0 && d.NP >= d.N, "bsed_igemm3s: NP must be N rounded up to 32");
+  d.tilesH = ceil_div(d.H, d.TH);
+  d.tilesW = d.W / d.TW;
+  P.PW = d.TW + 2 * d.hw;
+  P.PH = d.TH + 2 * d.hh;
+  P.PP = P.PW * P.PH;
+  BSED_CHECK_ARG(P.PP <= 256, "bsed_igemm3s: patch of %d positions exceeds the 256 supported", P.PP);
+  P.b_off = 0;
+  P.pw_magic = ((1 << 20) + P.PW - 1) / P.PW;
+  for (int pos = 0; pos < P.PP; ++pos)
+    BSED_CHECK_ARG(((pos * P.pw_magic) >> 20) == pos / P.PW, "bsed_igemm3s: internal: magic division fails for PW=%d", P.PW);
+  const long ntiles = (long)d.NB * d.tilesH * d.tilesW;
+  BSED_CHECK_ARG(ntiles < (1L << 31) && G > 0 && G <= ntiles, "bsed_igemm3s: G must be in 1..%ld tiles", ntiles);
+  const size_t bytes = (size_t)d.ntaps * 2 * 64 * 16 + (size_t)P.PP * I3S_ROW * 2;
+  dim3 grid((unsigned)G, d.NP / 32);
+  hipStream_t s = (hipStream_t)stream;
+  const bool st = d.epilogue == BSED_EPI_STATS;
+  if (d.ntaps == 9) {
+    if (st) hipLaunchKernelGGL((igemm3s_kernel<1, 9>), grid, dim3(I3_THREADS), bytes, s, P);
+    else hipLaunchKernelGGL((igemm3s_kernel<0, 9>), grid, dim3(I3_THREADS), bytes, s, P);
+  } else {
+    if (st) hipLaunchKernelGGL((igemm3s_kernel<1, 1>), grid, dim3(I3_THREADS), bytes, s, P);
+    else hipLaunchKernelGGL((igemm3s_kernel<0, 1>), grid, dim3(I3_THREADS), bytes, s, P);
+  }
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
 }

@@ -249,6 +249,9 @@ class CRNN(_FlatModule):
                 if self.conv_mode == "bf16x3" and cin % 32 == 0:
                     w3 = ops.pack_weight3(cw, 9, cin, co, 1, 9, cin * 9)
                     y, stats = ops.igemm3(a, w3, co, B, Hh, Ww, cin, ops.TAPS3x3, bias=cb, epilogue=epi)
+                elif self.conv_mode == "bf16x3" and cin == 16 and (128 // min(Ww, 16) + 2) * (min(Ww, 16) + 2) <= 256:
+                    w3s = ops.pack_weight3s(cw, 9, co, 1, 9, cin * 9)
+                    y, stats = ops.igemm3s(a, w3s, co, B, Hh, Ww, ops.TAPS3x3, bias=cb, epilogue=epi)
                 else:
                     wpk = ops.pack_weight(cw, 9, cin, co, 1, 9, cin * 9)
                     y, stats = ops.igemm(a, wpk, co, B, Hh, Ww, cin, taps=ops.TAPS3x3, bias=cb, epilogue=epi)

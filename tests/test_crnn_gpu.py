@@ -281,7 +281,9 @@ def test_mean_teacher_step_and_ema_match_reference_golden(golden_dir):
         for n in np.array(names)[keep]:
             key = f"ema{gs}/{n}"
             if key in g.files:
-                np.testing.assert_allclose(sd[n].cpu().numpy(), g[key], rtol=1e-4, atol=2e-5)
+                # atol = 0.1 * lr: the first Adam step is lr * g / (|g| + 1e-8), so an element whose gradient is at the
+                # 1e-8 scale moves by a fraction of lr that follows round-off level differences of g
+                np.testing.assert_allclose(sd[n].cpu().numpy(), g[key], rtol=1e-4, atol=1e-4)
 
 
 def test_train_step_from_waveforms_runs_mel_on_gpu():

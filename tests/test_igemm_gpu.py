@@ -261,3 +261,23 @@ def test_glu_backward_c128_split_fp32_matches_fp32_fused_kernel(B, H, W, pool):
                        ("bn sums", st2.sum(0), st.sum(0))):
         err = float((a - b).norm() / b.norm())
         assert err < 3e-5, (name, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,N", [(2, 40, 64, 32), (3, 21, 16, 32), (1, 9, 8, 64), (2, 300, 64, 32)])
+def test_conv_cin16_split_fp32_matches_torch(B, H, W, N):
+    """bsed_igemm3s (all taps' weights resident in LDS, persistent workgroups) vs F.conv2d, with the BatchNorm sums"""
+    from bsed_amd import ops
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(B, H, W, 16, generator=g).cuda()
+    w = (torch.randn(N, 16, 3, 3, generator=g) * 0.1).cuda()
+    bias = (torch.randn(N, generator=g) * 0.1).cuda()
+    wt = ops.pack_weight3s(w, 9, N, 1, 9, 16 * 9)
+    out, stats = ops.igemm3s(x, wt, N, B, H, W, ops.TAPS3x3, bias=bias, epilogue=ops.EPI_STATS)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+    assert float((out.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    tot = stats.double().sum(0)
+    assert float((tot[0] - ref.sum((0, 1, 2))).abs().max()) < 1e-3 * max(1.0, float(ref.sum((0, 1, 2)).abs().max()))
+    assert float((tot[1] - (ref * ref).sum((0, 1, 2))).abs().max()) < 1e-4 * float((ref * ref).sum((0, 1, 2)).max())
+    out2, _ = ops.igemm3s(x, wt, N, B, H, W, ops.TAPS3x3, bias=bias)
+    assert torch.equal(out, out2)
