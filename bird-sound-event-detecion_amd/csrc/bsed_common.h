@@ -40,6 +40,19 @@ void bsed_set_error(const char* fmt, ...);
   } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bsed_bf16x2 __attribute__((ext_vector_type(2)));
+
+// Split-fp32 operands: x = hi + lo with hi = bf16(x), lo = bf16(x - hi), both round-to-nearest-even.  gfx950 converts
+// two floats to a packed bf16 pair in ONE instruction (v_cvt_pk_bf16_f32); the integer-arithmetic rounding used before
+// cost ~11 VALU instructions per element and made the staging loops of the split-fp32 kernels issue-bound.
+//   hi / lo : packed pairs, element a in the low half
+__device__ __forceinline__ void bsed_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const f32x2 v = {a, b};
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bsed_bf16x2));
+  const f32x2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u)};
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bsed_bf16x2));
+}
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

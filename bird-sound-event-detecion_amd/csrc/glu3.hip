@@ -49,18 +49,24 @@ struct Glu3Params {
 // issue order, but the COMPILER may move a 16-byte fragment load above the 2-byte element stores that produce it (type
 // based alias analysis sees unrelated types; __builtin_amdgcn_wave_barrier() does not order memory operations).
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// The same fence for the point where accumulators that VALU code has just written (the gate term) become the SrcC of
+// the next MFMA.  Tying them to the asm makes the register allocator finish its copies into the accumulator tuples
+// BEFORE the wait, and the s_nop pads the VALU-write -> MFMA-SrcC distance: without it hipcc (ROCm 7.2) left a
+// `v_mov` into the tuple one `s_nop 0` ahead of the MFMA, and lanes 48..63 of that register (the last quarter a wave64
+// VALU instruction writes) were occasionally read stale -- one wrong position per ~10 runs of a 2.5 M element tensor.
+template <int NT>
+__device__ __forceinline__ void acc_handoff_fence(f32x16 (&acc)[NT]) {
+  if constexpr (NT == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" : "+v"(acc[0]) :: "memory");
+  else if constexpr (NT == 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]) :: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) :: "memory");
+}
 __device__ __forceinline__ int crow3g(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 __device__ __forceinline__ uint32_t rne_bits(float x) {  // bf16 round-to-nearest-even, result in the UPPER 16 bits
   const uint32_t u = __float_as_uint(x);
   return u + 0x7FFFu + ((u >> 16) & 1u);
 }
 // two fp32 values -> one packed word of bf16 hi parts and one of bf16 lo parts (element 0 in the low half)
-__device__ __forceinline__ void split_pack2(float a, float b, uint32_t& hi, uint32_t& lo) {
-  const uint32_t ua = rne_bits(a) & 0xFFFF0000u, ub = rne_bits(b) & 0xFFFF0000u;
-  const float la = a - __uint_as_float(ua), lb = b - __uint_as_float(ub);
-  hi = ub | (ua >> 16);
-  lo = (rne_bits(lb) & 0xFFFF0000u) | (rne_bits(la) >> 16);
-}
+__device__ __forceinline__ void split_pack2(float a, float b, uint32_t& hi, uint32_t& lo) { bsed_split2(a, b, hi, lo); }
 __device__ __forceinline__ void split_pack8(const float* v, bf16x8& hi, bf16x8& lo) {
   u32x4 h, l;
 #pragma unroll
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? 3 : 2) void glu_bwd3_kernel(c
         split_pack8(xn8[j], xb_hi[j][f], xb_lo[j][f]);
       }
     }
-    wave_lds_fence();  // the tile is wave-private: LDS operations of one wave execute in issue order
+    acc_handoff_fence<NT>(acc);  // the tile is wave-private: LDS operations of one wave execute in issue order
 
     // ---- GEMM2: g = d_lin W + gate term (already in acc)
 #pragma unroll
@@ -490,6 +496,7 @@ __global__ __launch_bounds__(G3_THREADS, 1) void glu_bwd3n_kernel(const Glu3Para
     }
 
     // ---- GEMM2 in four K quarters: g = d_lin W + gate term (already in acc)
+    acc_handoff_fence<NT>(acc);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll

@@ -179,6 +179,10 @@ __global__ __launch_bounds__(NW * 64) void glu_bwd_fused_kernel(const GluBwdPara
       }
     }
 
+    // (accumulators just written by VALU code become SrcC of the next MFMA: finish the copies into the tuples and
+    // pad the distance -- see acc_handoff_fence in glu3.hip)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) asm volatile("s_nop 7" : "+v"(acc[j]));
     // ---- GEMM2: g = d_lin W + gate term (already in acc); its A rows are this wave's own d_lin rows
     for (int k0 = 0; k0 < C; k0 += 32) {
       if (!RES) {

@@ -434,13 +434,23 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(const WgradParams P) {
 typedef short w3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t w3_u32x4 __attribute__((ext_vector_type(4)));
 
+// one element -> word (bf16 hi | bf16 lo << 16); two elements share the packed hardware conversions
+__device__ __forceinline__ void w3_split2(float a, float b, uint32_t& wa, uint32_t& wb) {
+  uint32_t hi, lo;
+  bsed_split2(a, b, hi, lo);
+  wa = __builtin_amdgcn_perm(lo, hi, 0x05040100u);  // (lo.a << 16) | hi.a
+  wb = __builtin_amdgcn_perm(lo, hi, 0x07060302u);  // (lo.b << 16) | hi.b
+}
+__device__ __forceinline__ uint4 w3_split4(float a, float b, float c, float d) {
+  uint4 r;
+  w3_split2(a, b, r.x, r.y);
+  w3_split2(c, d, r.z, r.w);
+  return r;
+}
 __device__ __forceinline__ uint32_t w3_split(float x) {
-  const uint32_t u = __float_as_uint(x);
-  const uint32_t hi = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-  const float r = x - __uint_as_float(hi << 16);
-  const uint32_t v = __float_as_uint(r);
-  const uint32_t lo = (v + 0x7FFFu + ((v >> 16) & 1u)) >> 16;
-  return hi | (lo << 16);
+  uint32_t wa, wb;
+  w3_split2(x, x, wa, wb);
+  return wa;
 }
 
 template <int MAXS, int NW>
@@ -520,7 +530,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(const WgradParams P) {
             v[u].z = fmaf(v[u].z, sc.z, sh.z); v[u].w = fmaf(v[u].w, sc.w, sh.w);
           }
           *reinterpret_cast<uint4*>(Xw + pos * CC + 4 * c4) =
-              make_uint4(w3_split(v[u].x), w3_split(v[u].y), w3_split(v[u].z), w3_split(v[u].w));
+              w3_split4(v[u].x, v[u].y, v[u].z, v[u].w);
         }
       }
     }
@@ -536,7 +546,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(const WgradParams P) {
       }
       uint32_t w[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) w[j] = w3_split(f[j]);
+      for (int j = 0; j < 8; j += 2) w3_split2(f[j], f[j + 1], w[j], w[j + 1]);
       uint4 hi, lo;
       hi.x = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u); lo.x = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
       hi.y = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u); lo.y = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);

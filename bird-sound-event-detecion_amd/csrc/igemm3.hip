@@ -94,15 +94,12 @@ void igemm3_kernel(const Igemm3Params P) {
     for (int u = 0; u < PV; ++u) {
       const int e = tid + u * I3_THREADS;
       if (e < a_total) {
-        unsigned short hi[4], lo[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          hi[i] = f2bf(pv[u][i]);
-          lo[i] = f2bf(pv[u][i] - bf2f(hi[i]));
-        }
+        uint32_t h01, l01, h23, l23;
+        bsed_split2(pv[u][0], pv[u][1], h01, l01);
+        bsed_split2(pv[u][2], pv[u][3], h23, l23);
         unsigned short* dst = As + (e >> 3) * I3_ROW + 4 * (e & 7);
-        *reinterpret_cast<uint2*>(dst) = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
-        *reinterpret_cast<uint2*>(dst + 32) = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(dst + 32) = make_uint2(l01, l23);
       }
     }
     // weight slab [BN][64] bf16 (hi | lo), pre-split: 128 B per output channel, NT uint4 per thread.  The slab of tap
@@ -366,15 +363,12 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
     for (int u = 0; u < PV; ++u) {
       const int e = tid + u * I3_THREADS;
       if (e < a_total) {
-        unsigned short hi[4], lo[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          hi[i] = f2bf(pv[u][i]);
-          lo[i] = f2bf(pv[u][i] - bf2f(hi[i]));
-        }
+        uint32_t h01, l01, h23, l23;
+        bsed_split2(pv[u][0], pv[u][1], h01, l01);
+        bsed_split2(pv[u][2], pv[u][3], h23, l23);
         unsigned short* dst = As + (e >> 2) * I3S_ROW + 4 * (e & 3);
-        *reinterpret_cast<uint2*>(dst) = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
-        *reinterpret_cast<uint2*>(dst + 16) = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(dst + 16) = make_uint2(l01, l23);
       }
     }
     __syncthreads();
