@@ -619,7 +619,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
     const int nb = tile / P.tilesH;
     const int th0 = th_i * P.TH, tw0 = tw_i * P.TW;
     int lhv = 4 * lh;
-    asm volatile("" : "+v"(lhv));
+    if (C > 64) asm volatile("" : "+v"(lhv));  // C <= 64 have registers to spare: let the per-row index math be hoisted
 
     f32x16 acc[NT];
     {
