@@ -285,20 +285,22 @@ extern "C" int bsed_pack_weight3(const float* src, void* dst, int ntaps, int K, 
 // weights of ALL taps in LDS (fragment order, 18 KB per 32 output channels, loaded once per persistent workgroup) and
 // only the activation patch moves per tile: [prefetched registers -> LDS] -> barrier -> 27 MFMAs per wave -> epilogue.
 // BatchNorm partial sums accumulate in registers over the tiles of a workgroup (one partial row per workgroup).
-#define I3S_ROW 40  // ushorts per patch row: 16 hi | 16 lo | 8 pad (80 B = 5 x 16 B)
+// (KS = CIN / 16 K steps per tap: 1 for the 16 -> 32 convolution, 2 for the data gradients of 32-channel layers)
 
-__global__ void pack_weight3s_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int ntaps, int N,
-                                     int NP, long s_tap, long s_k, long s_n) {
-  // table[jn][tap][hi|lo][lane][8]: lane (li, lh) holds k = 8*lh + q of output channel n = 32*jn + li
-  const long total = (long)(NP / 32) * ntaps * 64;
+__global__ void pack_weight3s_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int ntaps, int KS,
+                                     int N, int NP, long s_tap, long s_k, long s_n) {
+  // table[jn][tap][kk][hi|lo][lane][8]: lane (li, lh) holds k = 16*kk + 8*lh + q of output channel n = 32*jn + li
+  const long total = (long)(NP / 32) * ntaps * KS * 64;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int lane = (int)(e & 63), li = lane & 31, lh = lane >> 5;
-    const int tap = (int)((e >> 6) % ntaps), jn = (int)((e >> 6) / ntaps);
+    long r = e >> 6;
+    const int kk = (int)(r % KS); r /= KS;
+    const int tap = (int)(r % ntaps), jn = (int)(r / ntaps);
     const int n = 32 * jn + li;
-    unsigned short* d = dst + ((((long)jn * ntaps + tap) * 2) * 64 + lane) * 8;
+    unsigned short* d = dst + (((((long)jn * ntaps + tap) * KS + kk) * 2) * 64 + lane) * 8;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const float v = n < N ? src[tap * s_tap + (long)(8 * lh + q) * s_k + n * s_n] : 0.f;
+      const float v = n < N ? src[tap * s_tap + (long)(16 * kk + 8 * lh + q) * s_k + n * s_n] : 0.f;
       const unsigned short hi = f2bf(v);
       d[q] = hi;
       d[64 * 8 + q] = f2bf(v - bf2f(hi));
@@ -306,18 +308,21 @@ __global__ void pack_weight3s_kernel(const float* __restrict__ src, unsigned sho
   }
 }
 
-template <int STATS, int NTAPS>
+template <int STATS, int NTAPS, int KS>
 __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params P) {
-  constexpr int PV = 4;  // float4 patch elements per thread: up to 256 patch positions x 4
+  constexpr int CINK = 16 * KS;
+  constexpr int I3S_ROW = 2 * CINK + 8;  // ushorts per patch row: CIN hi | CIN lo | 8 pad (80 B / 144 B: odd x 16 B)
+  constexpr int C4 = CINK / 4;           // float4 per patch position
+  constexpr int PV = KS == 1 ? 4 : 6;    // float4 patch elements per thread: 256 x 4 / 192 x 8 patch elements
   const BsedIgemmDesc& p = P.d;
   extern __shared__ __align__(16) unsigned short smem3[];
-  u32x4* Wf = reinterpret_cast<u32x4*>(smem3);               // [NTAPS][2][64]
-  unsigned short* As = smem3 + NTAPS * 2 * 64 * 8;           // [PP][40]
+  u32x4* Wf = reinterpret_cast<u32x4*>(smem3);               // [NTAPS][KS][2][64]
+  unsigned short* As = smem3 + NTAPS * KS * 2 * 64 * 8;      // [PP][I3S_ROW]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int jn = blockIdx.y, n0 = 32 * jn;
   const int PW = P.PW;
-  for (int i = tid; i < NTAPS * 2 * 64; i += I3_THREADS)
-    Wf[i] = reinterpret_cast<const u32x4*>(p.w)[(size_t)jn * NTAPS * 2 * 64 + i];
+  for (int i = tid; i < NTAPS * KS * 2 * 64; i += I3_THREADS)
+    Wf[i] = reinterpret_cast<const u32x4*>(p.w)[(size_t)jn * NTAPS * KS * 2 * 64 + i];
   const int m = wave * 32 + li;
   const int abase = (((m >> P.lgTW) + p.hh) * PW + (m & (p.TW - 1)) + p.hw) * I3S_ROW + 8 * lh;
   int toff[NTAPS];
@@ -327,14 +332,14 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
   const bool nok = n < p.N;
   const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
   float s0 = 0.f, s1 = 0.f;
-  const int a_total = P.PP * 4;
+  const int a_total = P.PP * C4;
   const int ntiles = p.NB * p.tilesH * p.tilesW;
 
-  // patch element e = tid + u*256 -> (position e/4, channels 4*(e%4)..): tile-independent part of the address
+  // patch element e = tid + u*256 -> (position e/C4, channels 4*(e%C4)..): tile-independent part of the address
   int ppr[PV], ppc[PV];
 #pragma unroll
   for (int u = 0; u < PV; ++u) {
-    const int e = tid + u * I3_THREADS, pos = e >> 2;
+    const int e = tid + u * I3_THREADS, pos = e / C4;
     ppr[u] = (pos * P.pw_magic) >> 20;
     ppc[u] = pos - ppr[u] * PW;
   }
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
       const int e = tid + u * I3_THREADS;
       const int gh = th_i * p.TH - p.hh + ppr[u], gw = tw_i * p.TW - p.hw + ppc[u];
       const bool ok = e < a_total && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
-      pv[u] = ok ? *reinterpret_cast<const f32x4*>(inb + ((size_t)gh * p.W + gw) * p.in_pitch + 4 * (e & 3))
+      pv[u] = ok ? *reinterpret_cast<const f32x4*>(inb + ((size_t)gh * p.W + gw) * p.in_pitch + 4 * (e % C4))
                  : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
@@ -366,9 +371,9 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
         uint32_t h01, l01, h23, l23;
         bsed_split2(pv[u][0], pv[u][1], h01, l01);
         bsed_split2(pv[u][2], pv[u][3], h23, l23);
-        unsigned short* dst = As + (e >> 2) * I3S_ROW + 4 * (e & 3);
+        unsigned short* dst = As + (e / C4) * I3S_ROW + 4 * (e % C4);
         *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
-        *reinterpret_cast<uint2*>(dst + 16) = make_uint2(l01, l23);
+        *reinterpret_cast<uint2*>(dst + CINK) = make_uint2(l01, l23);
       }
     }
     __syncthreads();
@@ -377,19 +382,22 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    bf16x8 a_hi[NTAPS], a_lo[NTAPS];
 #pragma unroll
-    for (int t = 0; t < NTAPS; ++t) {
-      a_hi[t] = *reinterpret_cast<const bf16x8*>(As + abase + toff[t]);
-      a_lo[t] = *reinterpret_cast<const bf16x8*>(As + abase + toff[t] + 16);
-    }
+    for (int kk = 0; kk < KS; ++kk) {
+      bf16x8 a_hi[NTAPS], a_lo[NTAPS];
 #pragma unroll
-    for (int t = 0; t < NTAPS; ++t) {
-      const bf16x8 b_hi = __builtin_bit_cast(bf16x8, Wf[(t * 2 + 0) * 64 + lane]);
-      const bf16x8 b_lo = __builtin_bit_cast(bf16x8, Wf[(t * 2 + 1) * 64 + lane]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[t], b_hi, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[t], b_lo, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[t], b_hi, acc, 0, 0, 0);
+      for (int t = 0; t < NTAPS; ++t) {
+        a_hi[t] = *reinterpret_cast<const bf16x8*>(As + abase + toff[t] + 16 * kk);
+        a_lo[t] = *reinterpret_cast<const bf16x8*>(As + abase + toff[t] + CINK + 16 * kk);
+      }
+#pragma unroll
+      for (int t = 0; t < NTAPS; ++t) {
+        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, Wf[((t * KS + kk) * 2 + 0) * 64 + lane]);
+        const bf16x8 b_lo = __builtin_bit_cast(bf16x8, Wf[((t * KS + kk) * 2 + 1) * 64 + lane]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[t], b_hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[t], b_lo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[t], b_hi, acc, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -488,12 +496,13 @@ extern "C" int bsed_igemm3(const BsedIgemmDesc* desc, void* stream) {
 
 // ---- CIN = 16 variant: w = bsed_pack_weight3s table; persistent grid of G workgroups per 32 output channels;
 // stats (STATS epilogue) has G rows (one per workgroup), not one per tile
-extern "C" int bsed_pack_weight3s(const float* src, void* dst, int ntaps, int N, int NP, long s_tap, long s_k, long s_n,
-                                  void* stream) {
-  BSED_CHECK_ARG(src && dst && ntaps > 0 && N > 0 && NP >= N && NP % 32 == 0, "bsed_pack_weight3s: bad argument");
-  const long total = (long)(NP / 32) * ntaps * 64;
+extern "C" int bsed_pack_weight3s(const float* src, void* dst, int ntaps, int K, int N, int NP, long s_tap, long s_k,
+                                  long s_n, void* stream) {
+  BSED_CHECK_ARG(src && dst && ntaps > 0 && (K == 16 || K == 32) && N > 0 && NP >= N && NP % 32 == 0,
+                 "bsed_pack_weight3s: K must be 16 or 32, NP a multiple of 32 >= N");
+  const long total = (long)(NP / 32) * ntaps * (K / 16) * 64;
   hipLaunchKernelGGL(pack_weight3s_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
-                     (unsigned short*)dst, ntaps, N, NP, s_tap, s_k, s_n);
+                     (unsigned short*)dst, ntaps, K / 16, N, NP, s_tap, s_k, s_n);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }
@@ -508,7 +517,9 @@ extern "C" int bsed_igemm3s(const BsedIgemmDesc* desc, int G, void* stream) {
   BSED_CHECK_ARG(d.in && d.w && d.out, "bsed_igemm3s: null tensor");
   BSED_CHECK_ARG(d.epilogue == BSED_EPI_PLAIN || d.epilogue == BSED_EPI_STATS, "bsed_igemm3s: PLAIN / STATS epilogues only");
   BSED_CHECK_ARG(d.epilogue != BSED_EPI_STATS || d.stats, "bsed_igemm3s: STATS needs a stats buffer");
-  BSED_CHECK_ARG(d.NB > 0 && d.H > 0 && d.W > 0 && d.CIN == 16 && d.N > 0, "bsed_igemm3s: built for CIN = 16");
+  BSED_CHECK_ARG(d.NB > 0 && d.H > 0 && d.W > 0 && (d.CIN == 16 || d.CIN == 32) && d.N > 0,
+                 "bsed_igemm3s: built for CIN = 16 or 32");
+  const int KS = d.CIN / 16;
   BSED_CHECK_ARG(d.TH * d.TW == I3_M && d.W % d.TW == 0, "bsed_igemm3s: TH*TW must be 128 and TW divide W");
   P.lgTW = 0;
   while ((1 << P.lgTW) < d.TW) ++P.lgTW;
@@ -523,23 +534,30 @@ extern "C" int bsed_igemm3s(const BsedIgemmDesc* desc, int G, void* stream) {
   P.PW = d.TW + 2 * d.hw;
   P.PH = d.TH + 2 * d.hh;
   P.PP = P.PW * P.PH;
-  BSED_CHECK_ARG(P.PP <= 256, "bsed_igemm3s: patch of %d positions exceeds the 256 supported", P.PP);
+  BSED_CHECK_ARG(P.PP <= (KS == 1 ? 256 : 192), "bsed_igemm3s: patch of %d positions exceeds the %d supported", P.PP,
+                 KS == 1 ? 256 : 192);
   P.b_off = 0;
   P.pw_magic = ((1 << 20) + P.PW - 1) / P.PW;
   for (int pos = 0; pos < P.PP; ++pos)
     BSED_CHECK_ARG(((pos * P.pw_magic) >> 20) == pos / P.PW, "bsed_igemm3s: internal: magic division fails for PW=%d", P.PW);
   const long ntiles = (long)d.NB * d.tilesH * d.tilesW;
   BSED_CHECK_ARG(ntiles < (1L << 31) && G > 0 && G <= ntiles, "bsed_igemm3s: G must be in 1..%ld tiles", ntiles);
-  const size_t bytes = (size_t)d.ntaps * 2 * 64 * 16 + (size_t)P.PP * I3S_ROW * 2;
+  const size_t bytes = (size_t)d.ntaps * KS * 2 * 64 * 16 + (size_t)P.PP * (2 * d.CIN + 8) * 2;
   dim3 grid((unsigned)G, d.NP / 32);
   hipStream_t s = (hipStream_t)stream;
   const bool st = d.epilogue == BSED_EPI_STATS;
-  if (d.ntaps == 9) {
-    if (st) hipLaunchKernelGGL((igemm3s_kernel<1, 9>), grid, dim3(I3_THREADS), bytes, s, P);
-    else hipLaunchKernelGGL((igemm3s_kernel<0, 9>), grid, dim3(I3_THREADS), bytes, s, P);
+  if (d.ntaps == 9 && KS == 1) {
+    if (st) hipLaunchKernelGGL((igemm3s_kernel<1, 9, 1>), grid, dim3(I3_THREADS), bytes, s, P);
+    else hipLaunchKernelGGL((igemm3s_kernel<0, 9, 1>), grid, dim3(I3_THREADS), bytes, s, P);
+  } else if (d.ntaps == 9) {
+    if (st) hipLaunchKernelGGL((igemm3s_kernel<1, 9, 2>), grid, dim3(I3_THREADS), bytes, s, P);
+    else hipLaunchKernelGGL((igemm3s_kernel<0, 9, 2>), grid, dim3(I3_THREADS), bytes, s, P);
+  } else if (KS == 1) {
+    if (st) hipLaunchKernelGGL((igemm3s_kernel<1, 1, 1>), grid, dim3(I3_THREADS), bytes, s, P);
+    else hipLaunchKernelGGL((igemm3s_kernel<0, 1, 1>), grid, dim3(I3_THREADS), bytes, s, P);
   } else {
-    if (st) hipLaunchKernelGGL((igemm3s_kernel<1, 1>), grid, dim3(I3_THREADS), bytes, s, P);
-    else hipLaunchKernelGGL((igemm3s_kernel<0, 1>), grid, dim3(I3_THREADS), bytes, s, P);
+    if (st) hipLaunchKernelGGL((igemm3s_kernel<1, 1, 2>), grid, dim3(I3_THREADS), bytes, s, P);
+    else hipLaunchKernelGGL((igemm3s_kernel<0, 1, 2>), grid, dim3(I3_THREADS), bytes, s, P);
   }
   BSED_LAUNCH_CHECK();
   return BSED_OK;

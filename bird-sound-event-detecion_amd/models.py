@@ -249,7 +249,7 @@ class CRNN(_FlatModule):
                 if self.conv_mode == "bf16x3" and cin % 32 == 0:
                     w3 = ops.pack_weight3(cw, 9, cin, co, 1, 9, cin * 9)
                     y, stats = ops.igemm3(a, w3, co, B, Hh, Ww, cin, ops.TAPS3x3, bias=cb, epilogue=epi)
-                elif self.conv_mode == "bf16x3" and cin == 16 and (128 // min(Ww, 16) + 2) * (min(Ww, 16) + 2) <= 256:
+                elif self.conv_mode == "bf16x3" and cin == 16 and ops.igemm3s_supported(Ww, cin):
                     w3s = ops.pack_weight3s(cw, 9, co, 1, 9, cin * 9)
                     y, stats = ops.igemm3s(a, w3s, co, B, Hh, Ww, ops.TAPS3x3, bias=cb, epilogue=epi)
                 else:
@@ -406,7 +406,11 @@ class CRNN(_FlatModule):
             part, G, KP, NP = ops.wgrad(blk["inp"], dy, B, Hh, Ww, cin, co, taps=ops.TAPS3x3)
             ops.reduce_partials(part, G, 9, KP, NP, cin, co, cw.grad, 1, 9, cin * 9)
             flipped = [(-a, -b) for a, b in ops.TAPS3x3]
-            if self.conv_mode == "bf16x3":
+            if self.conv_mode == "bf16x3" and co == 32 and cin <= 32 and ops.igemm3s_supported(Ww, co):
+                # data gradient of a 32-channel layer: all taps' weights resident in LDS (csrc/igemm3.hip, igemm3s)
+                wds = ops.pack_weight3s(cw, 9, cin, 1, cin * 9, 9, K=co)
+                dpool, _ = ops.igemm3s(dy, wds, cin, B, Hh, Ww, flipped)
+            elif self.conv_mode == "bf16x3":
                 wd3 = ops.pack_weight3(cw, 9, co, cin, 1, cin * 9, 9)
                 dpool, _ = ops.igemm3(dy, wd3, cin, B, Hh, Ww, co, flipped)
             else:

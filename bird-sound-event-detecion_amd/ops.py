@@ -164,17 +164,24 @@ def pack_weight3(src, ntaps, K, N, s_tap, s_k, s_n):
     return dst
 
 
-def pack_weight3s(src, ntaps, N, s_tap, s_k, s_n):
-    """pre-split weights of a CIN = 16 convolution in fragment order: int16 (NP/32, ntaps, 2, 64, 8)"""
+def pack_weight3s(src, ntaps, N, s_tap, s_k, s_n, K=16):
+    """pre-split weights of a CIN = 16 / 32 convolution in fragment order: int16 (NP/32, ntaps, K/16, 2, 64, 8)"""
     NP = round_up(N, 32)
-    dst = torch.empty((NP // 32, ntaps, 2, 64, 8), device=src.device, dtype=torch.int16)
-    L.call("bsed_pack_weight3s", _fp(_dp(src)), ctypes.c_void_p(dst.data_ptr()), _i(ntaps), _i(N), _i(NP),
+    dst = torch.empty((NP // 32, ntaps, K // 16, 2, 64, 8), device=src.device, dtype=torch.int16)
+    L.call("bsed_pack_weight3s", _fp(_dp(src)), ctypes.c_void_p(dst.data_ptr()), _i(ntaps), _i(K), _i(N), _i(NP),
            ctypes.c_long(s_tap), ctypes.c_long(s_k), ctypes.c_long(s_n), L.stream())
     return dst
 
 
+def igemm3s_supported(W, CIN, ntaps=9):
+    TH, TW = tile_for(W)
+    halo = 1 if ntaps > 1 else 0
+    return CIN in (16, 32) and (TH + 2 * halo) * (TW + 2 * halo) <= (256 if CIN == 16 else 192)
+
+
 def igemm3s(inp, wtab, N, NB, H, W, taps, bias=None, epilogue=EPI_PLAIN):
-    """CIN = 16 convolution forward on the bf16 cores (split-fp32).  Returns (out, stats (G,2,N) or None)."""
+    """CIN = 16 / 32 convolution on the bf16 cores (split-fp32), all taps' weights resident in LDS.
+    Returns (out, stats (G,2,N) or None)."""
     d = IgemmDesc()
     TH, TW = tile_for(W)
     NP = wtab.shape[0] * 32
@@ -184,8 +191,9 @@ def igemm3s(inp, wtab, N, NB, H, W, taps, bias=None, epilogue=EPI_PLAIN):
     G = int(min(ntiles, L.lib().bsed_igemm3s_auto_g()))
     stats = torch.empty((G, 2, N), device=dev, dtype=torch.float32) if epilogue == EPI_STATS else None
     d.in_ = _dp(inp); d.w = wtab.data_ptr(); d.bias = _p(bias); d.out = _p(out); d.stats = _p(stats)
-    d.in_pitch, d.out_pitch, d.e_pitch = 16, N, N
-    d.NB, d.H, d.W, d.CIN, d.N, d.NP = NB, H, W, 16, N, NP
+    CIN = 16 * wtab.shape[2]
+    d.in_pitch, d.out_pitch, d.e_pitch = CIN, N, N
+    d.NB, d.H, d.W, d.CIN, d.N, d.NP = NB, H, W, CIN, N, NP
     d.TH, d.TW = TH, TW
     d.hh = max(abs(t[0]) for t in taps); d.hw = max(abs(t[1]) for t in taps)
     d.ntaps = len(taps)
@@ -193,8 +201,8 @@ def igemm3s(inp, wtab, N, NB, H, W, taps, bias=None, epilogue=EPI_PLAIN):
         d.dh[i], d.dw[i] = a, b
     d.ph = d.pw = 1; d.Hp, d.Wp = H, W
     d.epilogue = epilogue
-    _launch((f"igemm3s_kernel<{1 if epilogue == EPI_STATS else 0}, {len(taps)}>", len(taps), 16, N, H, W),
-            2.0 * NB * H * W * len(taps) * 16 * N, lambda: L.call("bsed_igemm3s", ctypes.byref(d), _i(G), L.stream()))
+    _launch((f"igemm3s_kernel<{1 if epilogue == EPI_STATS else 0}, {len(taps)}, {CIN // 16}>", len(taps), CIN, N, H, W),
+            2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call("bsed_igemm3s", ctypes.byref(d), _i(G), L.stream()))
     return out, stats
 
 

@@ -115,10 +115,11 @@ int bsed_igemm_num_tiles(const BsedIgemmDesc* desc /*host*/);
 int bsed_igemm3(const BsedIgemmDesc* desc /*host*/, void* stream);
 int bsed_pack_weight3(const float* src, void* dst, int ntaps, int K, int N, int NP, long s_tap, long s_k, long s_n,
                       void* stream);
-/* CIN = 16 variant (the 16 -> 32 channel convolution): weights of all taps stay in LDS, one MFMA K step per tap,
+/* CIN = 16 / 32 variant (the 16 -> 32 channel convolution, data gradients of 32-channel layers): weights of all taps
+ * stay in LDS, CIN/16 MFMA K steps per tap,
  * persistent grid of G workgroups per 32 output channels (bsed_igemm3s_auto_g()); desc as for bsed_igemm3 with
- * w = bsed_pack_weight3s table ((NP/32) * ntaps * 2 * 64 * 16 bytes); STATS writes G partial rows (one per workgroup). */
-int bsed_pack_weight3s(const float* src, void* dst, int ntaps, int N, int NP, long s_tap, long s_k, long s_n,
+ * w = bsed_pack_weight3s table ((NP/32) * ntaps * (K/16) * 2 * 64 * 16 bytes); STATS writes G partial rows (one per workgroup). */
+int bsed_pack_weight3s(const float* src, void* dst, int ntaps, int K, int N, int NP, long s_tap, long s_k, long s_n,
                        void* stream);
 int bsed_igemm3s(const BsedIgemmDesc* desc, int G, void* stream);
 int bsed_igemm3s_auto_g(void);

@@ -281,3 +281,19 @@ def test_conv_cin16_split_fp32_matches_torch(B, H, W, N):
     assert float((tot[1] - (ref * ref).sum((0, 1, 2))).abs().max()) < 1e-4 * float((ref * ref).sum((0, 1, 2)).max())
     out2, _ = ops.igemm3s(x, wt, N, B, H, W, ops.TAPS3x3, bias=bias)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,N", [(2, 40, 64, 16), (3, 21, 16, 16), (2, 300, 64, 32)])
+def test_dgrad_cin32_split_fp32_matches_torch(B, H, W, N):
+    """igemm3s with two K steps per tap: data gradient of a 32-channel 3x3 convolution (flipped taps, transposed weight)"""
+    from bsed_amd import ops
+    g = torch.Generator().manual_seed(H + W + N)
+    dy = torch.randn(B, H, W, 32, generator=g).cuda()
+    w = (torch.randn(32, N, 3, 3, generator=g) * 0.1).cuda()        # conv weight (Cout = 32, Cin = N)
+    wt = ops.pack_weight3s(w, 9, N, 1, N * 9, 9, K=32)              # [tap][k = cout][n = cin]
+    flipped = [(-a, -b) for a, b in ops.TAPS3x3]
+    assert ops.igemm3s_supported(W, 32)
+    dx, _ = ops.igemm3s(dy, wt, N, B, H, W, flipped)
+    ref = torch.nn.functional.conv_transpose2d(dy.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    assert float((dx.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
