@@ -102,3 +102,23 @@ def test_from_waveform_step_is_the_composition_of_mel_and_crnn_at_full_size():
         losses.append((SEDTrainer.loss_value(out), crnn.flat_grad.clone()))
     assert abs(losses[0][0] - losses[1][0]) < 1e-6 * abs(losses[0][0])
     assert torch.equal(losses[0][1], losses[1][1])
+
+
+def test_train_step_is_bitwise_repeatable_at_full_size():
+    """Two runs from the same state give bit-identical gradients (dropout on): every reduction in the path is ordered
+    (partial slabs + fixed-order sums, no float atomics on the CRNN path).  This check found a VALU -> MFMA SrcC
+    hand-off hazard (one stale element per ~10 runs) that no tolerance-based test could see."""
+    from bsed_amd.engine import FlatAdam, SEDTrainer
+    x = torch.from_numpy(seeded.db_like_input(12, B, T)).cuda()
+    y = torch.from_numpy(seeded.strong_targets(13, B, T // 4)).cuda()
+    grads = []
+    for rep in range(3):
+        crnn, pred = _models(0.5)
+        crnn.set_seed(5)
+        tr = SEDTrainer(crnn, pred, optimizer=FlatAdam([crnn, pred], lr=1e-3), seed=7)
+        junk = torch.empty((rep + 1) << 20, device="cuda")  # shift the allocator between repetitions
+        tr.train_step(x, y)
+        grads.append((crnn.flat_grad.clone(), pred.flat_grad.clone()))
+        del junk
+    for rep in (1, 2):
+        assert torch.equal(grads[0][0], grads[rep][0]) and torch.equal(grads[0][1], grads[rep][1])
