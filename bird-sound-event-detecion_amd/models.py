@@ -208,86 +208,75 @@ class CRNN(_FlatModule):
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     # ------------------------------------------------------------------ forward
-    def _rnn_views(self, l):
+    def _rnn_views(self, l, prefix="rnn"):
         H = self.n_hidden
         nin = self.nb_filters[-1] if l == 0 else 2 * H
         o = self._poff
-        w_ih = self.flat[o[f"rnn.rnn.weight_ih_l{l}"]:o[f"rnn.rnn.weight_ih_l{l}"] + 6 * H * nin]
-        w_hh = self.flat[o[f"rnn.rnn.weight_hh_l{l}"]:o[f"rnn.rnn.weight_hh_l{l}"] + 6 * H * H]
-        b_ih = self.flat[o[f"rnn.rnn.bias_ih_l{l}"]:o[f"rnn.rnn.bias_ih_l{l}"] + 6 * H]
-        b_hh = self.flat[o[f"rnn.rnn.bias_hh_l{l}"]:o[f"rnn.rnn.bias_hh_l{l}"] + 6 * H]
+        base = f"{prefix}.rnn."
+        w_ih = self.flat[o[f"{base}weight_ih_l{l}"]:o[f"{base}weight_ih_l{l}"] + 6 * H * nin]
+        w_hh = self.flat[o[f"{base}weight_hh_l{l}"]:o[f"{base}weight_hh_l{l}"] + 6 * H * H]
+        b_ih = self.flat[o[f"{base}bias_ih_l{l}"]:o[f"{base}bias_ih_l{l}"] + 6 * H]
+        b_hh = self.flat[o[f"{base}bias_hh_l{l}"]:o[f"{base}bias_hh_l{l}"] + 6 * H]
         return nin, w_ih, w_hh, b_ih, b_hh
 
-    def _rnn_grads(self, l):
+    def _rnn_grads(self, l, prefix="rnn"):
         H = self.n_hidden
         nin = self.nb_filters[-1] if l == 0 else 2 * H
         o, g = self._poff, self.flat_grad
-        return (g[o[f"rnn.rnn.weight_ih_l{l}"]:o[f"rnn.rnn.weight_ih_l{l}"] + 6 * H * nin],
-                g[o[f"rnn.rnn.weight_hh_l{l}"]:o[f"rnn.rnn.weight_hh_l{l}"] + 6 * H * H],
-                g[o[f"rnn.rnn.bias_ih_l{l}"]:o[f"rnn.rnn.bias_ih_l{l}"] + 6 * H],
-                g[o[f"rnn.rnn.bias_hh_l{l}"]:o[f"rnn.rnn.bias_hh_l{l}"] + 6 * H])
+        base = f"{prefix}.rnn."
+        return (g[o[f"{base}weight_ih_l{l}"]:o[f"{base}weight_ih_l{l}"] + 6 * H * nin],
+                g[o[f"{base}weight_hh_l{l}"]:o[f"{base}weight_hh_l{l}"] + 6 * H * H],
+                g[o[f"{base}bias_ih_l{l}"]:o[f"{base}bias_ih_l{l}"] + 6 * H],
+                g[o[f"{base}bias_hh_l{l}"]:o[f"{base}bias_hh_l{l}"] + 6 * H])
 
-    def run_forward(self, x, save=True):
-        """x: (B,1,T,F) fp32 GPU tensor.  Returns (enc (B,T',256), ctx for run_backward or None)."""
-        if x.dim() != 4 or x.shape[1] != 1:
-            raise L.BsedError(f"CRNN expects (B,1,T,F), got {tuple(x.shape)}")
-        x = x.contiguous().float()
-        B, _, Hh, Ww = x.shape
-        train = self.training
-        drop = self.dropout_p if train else 0.0
-        ctx = {"B": B, "blocks": [], "train": train, "seed": self.seed, "x": x} if save else None
-        a, cin = x, 1
-        for i, co in enumerate(self.nb_filters):
-            ph, pw = self.pooling[i]
-            if Ww % pw or Ww < 2 and pw > 1:
-                raise L.BsedError(f"block {i}: width {Ww} not divisible by the pooling window")
-            cw, cb = self.P(f"cnn.conv{i}.weight"), self.P(f"cnn.conv{i}.bias")
-            if i == 0:
-                y, stats = ops.conv0_fwd(a, cw, cb, B, Hh, Ww, co, want_stats=train)
+    # ------------------------------------------------------------------ building blocks
+    def _block_forward(self, a, B, Hh, Ww, cin, co, pool, names, drop, rng_stream, nbt, train, first=False):
+        """conv3x3 -> BatchNorm -> GLU -> Dropout -> AvgPool (reference src/models/CNN.py:46-67).  names = (conv, bn,
+        glu-linear) parameter prefixes.  Returns (pooled, saved-for-backward dict)."""
+        ph, pw = pool
+        cw, cb = self.P(names[0] + ".weight"), self.P(names[0] + ".bias")
+        if first:
+            y, stats = ops.conv0_fwd(a, cw, cb, B, Hh, Ww, co, want_stats=train)
+        else:
+            epi = ops.EPI_STATS if train else ops.EPI_PLAIN
+            if self.conv_mode == "bf16x3" and cin % 32 == 0:
+                w3 = ops.pack_weight3(cw, 9, cin, co, 1, 9, cin * 9)
+                y, stats = ops.igemm3(a, w3, co, B, Hh, Ww, cin, ops.TAPS3x3, bias=cb, epilogue=epi)
+            elif self.conv_mode == "bf16x3" and cin == 16 and ops.igemm3s_supported(Ww, cin):
+                w3s = ops.pack_weight3s(cw, 9, co, 1, 9, cin * 9)
+                y, stats = ops.igemm3s(a, w3s, co, B, Hh, Ww, ops.TAPS3x3, bias=cb, epilogue=epi)
             else:
-                epi = ops.EPI_STATS if train else ops.EPI_PLAIN
-                if self.conv_mode == "bf16x3" and cin % 32 == 0:
-                    w3 = ops.pack_weight3(cw, 9, cin, co, 1, 9, cin * 9)
-                    y, stats = ops.igemm3(a, w3, co, B, Hh, Ww, cin, ops.TAPS3x3, bias=cb, epilogue=epi)
-                elif self.conv_mode == "bf16x3" and cin == 16 and ops.igemm3s_supported(Ww, cin):
-                    w3s = ops.pack_weight3s(cw, 9, co, 1, 9, cin * 9)
-                    y, stats = ops.igemm3s(a, w3s, co, B, Hh, Ww, ops.TAPS3x3, bias=cb, epilogue=epi)
-                else:
-                    wpk = ops.pack_weight(cw, 9, cin, co, 1, 9, cin * 9)
-                    y, stats = ops.igemm(a, wpk, co, B, Hh, Ww, cin, taps=ops.TAPS3x3, bias=cb, epilogue=epi)
-            bn = self.P(f"cnn.batchnorm{i}")
-            if train:
-                mean, invstd, scale, shift = ops.bn_finalize(stats, co, float(B * Hh * Ww), BN_EPS, BN_MOMENTUM,
-                                                             bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                                             self.nbt[i:i + 1])
-            else:
-                mean = invstd = None
-                scale, shift = ops.bn_eval(co, BN_EPS, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-            glu = self.P(f"cnn.glu{i}.linear")
-            if co == 16:
-                # 4 FLOP/B: HBM-bound streaming kernel instead of the MFMA tile kernel (csrc/glu_small.hip)
-                pooled = ops.glu16_fwd(y, scale, shift, glu.weight, glu.bias, B, Hh, Ww, (ph, pw), drop, 100 + i,
-                                       self.seed)
-            elif self.conv_mode == "bf16x3" and self.glu3 and ops.glu_fwd3_supported(Ww, co, (ph, pw)):
-                pooled = ops.glu_fwd3(y, scale, shift, glu.weight, glu.bias, B, Hh, Ww, co, (ph, pw), drop, 100 + i,
-                                      self.seed)
-            else:
-                wg = ops.pack_weight(glu.weight, 1, co, co, 0, 1, co)
-                pooled, _ = ops.igemm(y, wg, co, B, Hh, Ww, co, bias=glu.bias, epilogue=ops.EPI_GLU_POOL,
-                                      a_scale=scale, a_shift=shift, e_src=y, e_scale=scale, e_shift=shift,
-                                      pool=(ph, pw), drop_p=drop, rng_stream=100 + i, seed=self.seed)
-            if save:
-                ctx["blocks"].append(dict(inp=a, y=y, mean=mean, invstd=invstd, scale=scale, shift=shift, H=Hh, W=Ww,
-                                          cin=cin, co=co, pool=(ph, pw)))
-            a, cin = pooled, co
-            Hh, Ww = Hh // ph, Ww // pw
-        if Ww != 1:
-            raise L.BsedError(f"frequency axis must pool down to 1, got {Ww}")
-        T = Hh
-        seq = a.view(B, T, cin)
+                wpk = ops.pack_weight(cw, 9, cin, co, 1, 9, cin * 9)
+                y, stats = ops.igemm(a, wpk, co, B, Hh, Ww, cin, taps=ops.TAPS3x3, bias=cb, epilogue=epi)
+        bn = self.P(names[1])
+        if train:
+            mean, invstd, scale, shift = ops.bn_finalize(stats, co, float(B * Hh * Ww), BN_EPS, BN_MOMENTUM,
+                                                         bn.weight, bn.bias, bn.running_mean, bn.running_var, nbt)
+        else:
+            mean = invstd = None
+            scale, shift = ops.bn_eval(co, BN_EPS, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        glu = self.P(names[2])
+        if co == 16:
+            # 4 FLOP/B: HBM-bound streaming kernel instead of the MFMA tile kernel (csrc/glu_small.hip)
+            pooled = ops.glu16_fwd(y, scale, shift, glu.weight, glu.bias, B, Hh, Ww, (ph, pw), drop, rng_stream,
+                                   self.seed)
+        elif self.conv_mode == "bf16x3" and self.glu3 and ops.glu_fwd3_supported(Ww, co, (ph, pw)):
+            pooled = ops.glu_fwd3(y, scale, shift, glu.weight, glu.bias, B, Hh, Ww, co, (ph, pw), drop, rng_stream,
+                                  self.seed)
+        else:
+            wg = ops.pack_weight(glu.weight, 1, co, co, 0, 1, co)
+            pooled, _ = ops.igemm(y, wg, co, B, Hh, Ww, co, bias=glu.bias, epilogue=ops.EPI_GLU_POOL,
+                                  a_scale=scale, a_shift=shift, e_src=y, e_scale=scale, e_shift=shift,
+                                  pool=(ph, pw), drop_p=drop, rng_stream=rng_stream, seed=self.seed)
+        blk = dict(inp=a, y=y, mean=mean, invstd=invstd, scale=scale, shift=shift, H=Hh, W=Ww, cin=cin, co=co,
+                   pool=(ph, pw), names=names, drop=drop, rng=rng_stream, first=first)
+        return pooled, blk
+
+    def _gru_forward(self, seq, B, T, prefix, save):
+        """2-layer BiGRU (reference src/models/RNN.py:7-16): input projections as one GEMM, then the recurrence"""
         layers = []
         for l in range(2):
-            nin, w_ih, w_hh, b_ih, b_hh = self._rnn_views(l)
+            nin, w_ih, w_hh, b_ih, b_hh = self._rnn_views(l, prefix)
             if self.conv_mode == "bf16x3":
                 w3 = ops.pack_weight3(w_ih, 1, nin, 768, 0, 1, nin)
                 xp, _ = ops.igemm3(seq, w3, 768, 1, B * T, 1, nin, ((0, 0),), bias=b_ih)
@@ -297,23 +286,14 @@ class CRNN(_FlatModule):
             out, gates = ops.gru_fwd(xp.view(B, T, 768), w_hh, b_hh, B, T, save_gates=save, mode=self.conv_mode)
             layers.append(dict(inp=seq, out=out, gates=gates))
             seq = out
-        enc = ops.dropout(seq, drop, 200, self.seed) if drop > 0 else seq
-        if save:
-            ctx.update(T=T, layers=layers, drop=drop)
-        return enc, ctx
+        return seq, layers
 
-    # ------------------------------------------------------------------ backward
-    def run_backward(self, ctx, d_enc):
-        """Accumulates parameter gradients into ``flat_grad``; returns nothing (the input needs no grad)."""
-        B, T = ctx["B"], ctx["T"]
-        seed = ctx["seed"]
-        d = d_enc.contiguous()
-        if ctx["drop"] > 0:
-            d = ops.dropout(d, ctx["drop"], 200, seed)
+    def _gru_backward(self, layers, d, B, T, prefix):
+        """returns dL/d(input sequence) (B,T,nin of layer 0); parameter gradients accumulate into flat_grad"""
         for l in (1, 0):
-            nin, w_ih, w_hh, b_ih, b_hh = self._rnn_views(l)
-            g_wih, g_whh, g_bih, g_bhh = self._rnn_grads(l)
-            lay = ctx["layers"][l]
+            nin, w_ih, w_hh, b_ih, b_hh = self._rnn_views(l, prefix)
+            g_wih, g_whh, g_bih, g_bhh = self._rnn_grads(l, prefix)
+            lay = layers[l]
             dxp, dgh, pih, phh = ops.gru_bwd(d, lay["out"], lay["gates"], w_hh, B, T, mode=self.conv_mode)
             if pih is not None:  # the recurrence kernel already summed the bias gradients over time per batch row
                 ops.colsum(pih, pih.shape[0], 768, 768, g_bih)
@@ -334,88 +314,142 @@ class CRNN(_FlatModule):
                 wpk = ops.pack_weight(w_ih, 1, 768, nin, 0, nin, 1)
                 d, _ = ops.igemm(dxp, wpk, nin, 1, B * T, 1, 768)
             d = d.view(B, T, nin)
+        return d
+
+    def _block_backward(self, blk, dpool, B, seed, need_dgrad=True):
+        """backward of one conv/BN/GLU/dropout/pool block; returns dL/d(block input) or None for the first block"""
+        Hh, Ww, cin, co = blk["H"], blk["W"], blk["cin"], blk["co"]
+        ph, pw = blk["pool"]
+        y = blk["y"]
+        conv_n, bn_n, glu_n = blk["names"]
+        glu, bn = self.P(glu_n), self.P(bn_n)
+        drop_b, rng = blk["drop"], blk["rng"]
+        if co == 16:
+            # one streaming pass: y, d_pooled -> g + partials of dW_glu, db_glu and the BN-backward sums
+            g, pdw, pdb, st2, G = ops.glu16_bwd(y, blk["scale"], blk["shift"], glu.weight, glu.bias,
+                                                dpool.contiguous(), B, Hh, Ww, (ph, pw), drop_b, rng, seed)
+            ops.reduce_partials(pdw, G, 1, 16, 16, 16, 16, glu.weight.grad, 0, 16, 1)
+            ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
+        elif co in (32, 64) and self.fused_glu_bwd and self.conv_mode == "bf16x3" and self.glu3:
+            # all three contractions on the bf16 cores, operands fetched in MFMA register layout (csrc/glu3.hip)
+            g, pdw, pdb, st2, G, slabs = ops.glu_bwd3(y, blk["scale"], blk["shift"], glu.weight, glu.bias,
+                                                      dpool.contiguous(), B, Hh, Ww, co, (ph, pw), drop_b, rng, seed)
+            ops.reduce_partials(pdw, G * slabs, 1, co, co, co, co, glu.weight.grad, 0, co, 1)
+            ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
+        elif co == 128 and self.fused_glu_bwd and self.conv_mode == "bf16x3" and self.glu3:
+            # lin recompute + g on the bf16 cores; d_lin goes through HBM to a 1-tap weight-gradient contraction
+            g, dlin, pdb, st2, G = ops.glu_bwd3n(y, blk["scale"], blk["shift"], glu.weight, glu.bias,
+                                                 dpool.contiguous(), B, Hh, Ww, co, (ph, pw), drop_b, rng, seed)
+            ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
+            part, Gw, KP, NP = ops.wgrad(y, dlin, B, Hh, Ww, co, co, a_scale=blk["scale"], a_shift=blk["shift"])
+            ops.reduce_partials(part, Gw, 1, KP, NP, co, co, glu.weight.grad, 0, 1, co)
+            del dlin
+        elif co in (32, 64, 128) and self.fused_glu_bwd:
+            # three chained MFMA contractions per tile, y read once, g written once (csrc/glu_bwd.hip)
+            wfwd = ops.pack_weight(glu.weight, 1, co, co, 0, 1, co)
+            g, pdw, pdb, st2, G, slabs = ops.glu_bwd_fused(y, blk["scale"], blk["shift"], wfwd, glu.weight,
+                                                           glu.bias, dpool.contiguous(), B, Hh, Ww, co, (ph, pw),
+                                                           drop_b, rng, seed)
+            ops.reduce_partials(pdw, G * slabs, 1, co, co, co, co, glu.weight.grad, 0, co, 1)
+            ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
+        else:
+            # (1) recompute lin, form d_lin and the gate-branch term
+            wg = ops.pack_weight(glu.weight, 1, co, co, 0, 1, co)
+            tt = torch.empty_like(y)
+            dlin, st = ops.igemm(y, wg, co, B, Hh, Ww, co, bias=glu.bias, epilogue=ops.EPI_GLU_BWD,
+                                 a_scale=blk["scale"], a_shift=blk["shift"], e_src=y, e_scale=blk["scale"],
+                                 e_shift=blk["shift"], e_dpool=dpool, out2=tt, pool=(ph, pw), drop_p=drop_b,
+                                 rng_stream=rng, seed=seed)
+            ops.stats_to_grad(st, co, 0, glu.bias.grad)
+            # (2) dW_glu = d_lin^T @ bn(y)
+            part, G, KP, NP = ops.wgrad(y, dlin, B, Hh, Ww, co, co, a_scale=blk["scale"], a_shift=blk["shift"])
+            ops.reduce_partials(part, G, 1, KP, NP, co, co, glu.weight.grad, 0, 1, co)
+            # (3) g = d_lin @ W_glu + gate term  (gradient w.r.t. the BatchNorm output), with BN-backward sums
+            wgT = ops.pack_weight(glu.weight, 1, co, co, 0, co, 1)
+            g, st2 = ops.igemm(dlin, wgT, co, B, Hh, Ww, co, epilogue=ops.EPI_ADD_STATS2, out=tt, out2=tt, e_src=y)
+        cw = self.P(conv_n + ".weight")
+        # conv bias feeds a train-mode BatchNorm: its gradient is exactly zero (DESIGN.md), leave it
+        if blk["first"]:
+            # (4') the first block's d_y is only consumed by conv0's weight gradient: BatchNorm backward is applied
+            # on load there, the largest tensor of the network is neither rewritten nor re-read
+            coef = ops.bn_bwd(st2, co, float(B * Hh * Ww), bn.weight, blk["mean"], blk["invstd"], bn.weight.grad,
+                              bn.bias.grad, g, y, apply=False)
+            part, G = ops.conv0_wgrad(blk["inp"], g, B, Hh, Ww, co, y=y, coef=coef, mean=blk["mean"])
+            ops.reduce_partials(part, G, 9, 1, co, 1, co, cw.grad, 1, 9, 9)
+            return None
+        # (4) BatchNorm backward -> d_y in place
+        ops.bn_bwd(st2, co, float(B * Hh * Ww), bn.weight, blk["mean"], blk["invstd"], bn.weight.grad,
+                   bn.bias.grad, g, y)
+        dy = g
+        part, G, KP, NP = ops.wgrad(blk["inp"], dy, B, Hh, Ww, cin, co, taps=ops.TAPS3x3)
+        ops.reduce_partials(part, G, 9, KP, NP, cin, co, cw.grad, 1, 9, cin * 9)
+        if not need_dgrad:
+            return None
+        flipped = [(-a, -b) for a, b in ops.TAPS3x3]
+        if self.conv_mode == "bf16x3" and co == 32 and cin <= 32 and ops.igemm3s_supported(Ww, co):
+            # data gradient of a 32-channel layer: all taps' weights resident in LDS (csrc/igemm3.hip, igemm3s)
+            wds = ops.pack_weight3s(cw, 9, cin, 1, cin * 9, 9, K=co)
+            d_in, _ = ops.igemm3s(dy, wds, cin, B, Hh, Ww, flipped)
+        elif self.conv_mode == "bf16x3":
+            wd3 = ops.pack_weight3(cw, 9, co, cin, 1, cin * 9, 9)
+            d_in, _ = ops.igemm3(dy, wd3, cin, B, Hh, Ww, co, flipped)
+        else:
+            wd = ops.pack_weight(cw, 9, co, cin, 1, cin * 9, 9)
+            d_in, _ = ops.igemm(dy, wd, cin, B, Hh, Ww, co, taps=flipped)
+        return d_in
+
+    def _cnn_forward(self, x, ctx):
+        """the seven conv/BN/GLU/dropout/pool blocks; returns (a (B,T',1,C), T')"""
+        B, _, Hh, Ww = x.shape
+        train = self.training
+        drop = self.dropout_p if train else 0.0
+        a, cin = x, 1
+        for i, co in enumerate(self.nb_filters):
+            ph, pw = self.pooling[i]
+            if Ww % pw or Ww < 2 and pw > 1:
+                raise L.BsedError(f"block {i}: width {Ww} not divisible by the pooling window")
+            names = (f"cnn.conv{i}", f"cnn.batchnorm{i}", f"cnn.glu{i}.linear")
+            a, blk = self._block_forward(a, B, Hh, Ww, cin, co, (ph, pw), names, drop, 100 + i, self.nbt[i:i + 1],
+                                         train, first=(i == 0))
+            if ctx is not None:
+                ctx["blocks"].append(blk)
+            cin = co
+            Hh, Ww = Hh // ph, Ww // pw
+        if Ww != 1:
+            raise L.BsedError(f"frequency axis must pool down to 1, got {Ww}")
+        return a, Hh
+
+    def _cnn_backward(self, ctx, dpool):
+        for i in range(len(self.nb_filters) - 1, -1, -1):
+            dpool = self._block_backward(ctx["blocks"][i], dpool, ctx["B"], ctx["seed"])
+
+    def run_forward(self, x, save=True):
+        """x: (B,1,T,F) fp32 GPU tensor.  Returns (enc (B,T',256), ctx for run_backward or None)."""
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise L.BsedError(f"CRNN expects (B,1,T,F), got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        B = x.shape[0]
+        train = self.training
+        drop = self.dropout_p if train else 0.0
+        ctx = {"B": B, "blocks": [], "train": train, "seed": self.seed, "x": x} if save else None
+        a, T = self._cnn_forward(x, ctx)
+        seq, layers = self._gru_forward(a.view(B, T, self.nb_filters[-1]), B, T, "rnn", save)
+        enc = ops.dropout(seq, drop, 200, self.seed) if drop > 0 else seq
+        if save:
+            ctx.update(T=T, layers=layers, drop=drop)
+        return enc, ctx
+
+    # ------------------------------------------------------------------ backward
+    def run_backward(self, ctx, d_enc):
+        """Accumulates parameter gradients into ``flat_grad``; returns nothing (the input needs no grad)."""
+        B, T = ctx["B"], ctx["T"]
+        d = d_enc.contiguous()
+        if ctx["drop"] > 0:
+            d = ops.dropout(d, ctx["drop"], 200, ctx["seed"])
+        d = self._gru_backward(ctx["layers"], d, B, T, "rnn")
         if not self.train_cnn:
             return
-        dpool = d.view(B, T, 1, self.nb_filters[-1])
-        for i in range(len(self.nb_filters) - 1, -1, -1):
-            blk = ctx["blocks"][i]
-            Hh, Ww, cin, co = blk["H"], blk["W"], blk["cin"], blk["co"]
-            ph, pw = blk["pool"]
-            y = blk["y"]
-            glu = self.P(f"cnn.glu{i}.linear")
-            bn = self.P(f"cnn.batchnorm{i}")
-            drop_b = ctx["drop"] if ctx["train"] else 0.0
-            if co == 16:
-                # one streaming pass: y, d_pooled -> g + partials of dW_glu, db_glu and the BN-backward sums
-                g, pdw, pdb, st2, G = ops.glu16_bwd(y, blk["scale"], blk["shift"], glu.weight, glu.bias,
-                                                    dpool.contiguous(), B, Hh, Ww, (ph, pw), drop_b, 100 + i, seed)
-                ops.reduce_partials(pdw, G, 1, 16, 16, 16, 16, glu.weight.grad, 0, 16, 1)
-                ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
-            elif co in (32, 64) and self.fused_glu_bwd and self.conv_mode == "bf16x3" and self.glu3:
-                # all three contractions on the bf16 cores, operands fetched in MFMA register layout (csrc/glu3.hip)
-                g, pdw, pdb, st2, G, slabs = ops.glu_bwd3(y, blk["scale"], blk["shift"], glu.weight, glu.bias,
-                                                          dpool.contiguous(), B, Hh, Ww, co, (ph, pw), drop_b, 100 + i,
-                                                          seed)
-                ops.reduce_partials(pdw, G * slabs, 1, co, co, co, co, glu.weight.grad, 0, co, 1)
-                ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
-            elif co == 128 and self.fused_glu_bwd and self.conv_mode == "bf16x3" and self.glu3:
-                # lin recompute + g on the bf16 cores; d_lin goes through HBM to a 1-tap weight-gradient contraction
-                g, dlin, pdb, st2, G = ops.glu_bwd3n(y, blk["scale"], blk["shift"], glu.weight, glu.bias,
-                                                     dpool.contiguous(), B, Hh, Ww, co, (ph, pw), drop_b, 100 + i, seed)
-                ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
-                part, Gw, KP, NP = ops.wgrad(y, dlin, B, Hh, Ww, co, co, a_scale=blk["scale"], a_shift=blk["shift"])
-                ops.reduce_partials(part, Gw, 1, KP, NP, co, co, glu.weight.grad, 0, 1, co)
-                del dlin
-            elif co in (32, 64, 128) and self.fused_glu_bwd:
-                # three chained MFMA contractions per tile, y read once, g written once (csrc/glu_bwd.hip)
-                wfwd = ops.pack_weight(glu.weight, 1, co, co, 0, 1, co)
-                g, pdw, pdb, st2, G, slabs = ops.glu_bwd_fused(y, blk["scale"], blk["shift"], wfwd, glu.weight,
-                                                               glu.bias, dpool.contiguous(), B, Hh, Ww, co, (ph, pw),
-                                                               drop_b, 100 + i, seed)
-                ops.reduce_partials(pdw, G * slabs, 1, co, co, co, co, glu.weight.grad, 0, co, 1)
-                ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
-            else:
-                # (1) recompute lin, form d_lin and the gate-branch term
-                wg = ops.pack_weight(glu.weight, 1, co, co, 0, 1, co)
-                tt = torch.empty_like(y)
-                dlin, st = ops.igemm(y, wg, co, B, Hh, Ww, co, bias=glu.bias, epilogue=ops.EPI_GLU_BWD,
-                                     a_scale=blk["scale"], a_shift=blk["shift"], e_src=y, e_scale=blk["scale"],
-                                     e_shift=blk["shift"], e_dpool=dpool, out2=tt, pool=(ph, pw), drop_p=drop_b,
-                                     rng_stream=100 + i, seed=seed)
-                ops.stats_to_grad(st, co, 0, glu.bias.grad)
-                # (2) dW_glu = d_lin^T @ bn(y)
-                part, G, KP, NP = ops.wgrad(y, dlin, B, Hh, Ww, co, co, a_scale=blk["scale"], a_shift=blk["shift"])
-                ops.reduce_partials(part, G, 1, KP, NP, co, co, glu.weight.grad, 0, 1, co)
-                # (3) g = d_lin @ W_glu + gate term  (gradient w.r.t. the BatchNorm output), with BN-backward sums
-                wgT = ops.pack_weight(glu.weight, 1, co, co, 0, co, 1)
-                g, st2 = ops.igemm(dlin, wgT, co, B, Hh, Ww, co, epilogue=ops.EPI_ADD_STATS2, out=tt, out2=tt, e_src=y)
-            cw = self.P(f"cnn.conv{i}.weight")
-            # conv bias feeds a train-mode BatchNorm: its gradient is exactly zero, leave it
-            if i == 0:
-                # (4') the first block's d_y is only consumed by conv0's weight gradient: BatchNorm backward is applied
-                # on load there, the largest tensor of the network is neither rewritten nor re-read
-                coef = ops.bn_bwd(st2, co, float(B * Hh * Ww), bn.weight, blk["mean"], blk["invstd"], bn.weight.grad,
-                                  bn.bias.grad, g, y, apply=False)
-                part, G = ops.conv0_wgrad(blk["inp"], g, B, Hh, Ww, co, y=y, coef=coef, mean=blk["mean"])
-                ops.reduce_partials(part, G, 9, 1, co, 1, co, cw.grad, 1, 9, 9)
-                continue
-            # (4) BatchNorm backward -> d_y in place
-            ops.bn_bwd(st2, co, float(B * Hh * Ww), bn.weight, blk["mean"], blk["invstd"], bn.weight.grad,
-                       bn.bias.grad, g, y)
-            dy = g
-            part, G, KP, NP = ops.wgrad(blk["inp"], dy, B, Hh, Ww, cin, co, taps=ops.TAPS3x3)
-            ops.reduce_partials(part, G, 9, KP, NP, cin, co, cw.grad, 1, 9, cin * 9)
-            flipped = [(-a, -b) for a, b in ops.TAPS3x3]
-            if self.conv_mode == "bf16x3" and co == 32 and cin <= 32 and ops.igemm3s_supported(Ww, co):
-                # data gradient of a 32-channel layer: all taps' weights resident in LDS (csrc/igemm3.hip, igemm3s)
-                wds = ops.pack_weight3s(cw, 9, cin, 1, cin * 9, 9, K=co)
-                dpool, _ = ops.igemm3s(dy, wds, cin, B, Hh, Ww, flipped)
-            elif self.conv_mode == "bf16x3":
-                wd3 = ops.pack_weight3(cw, 9, co, cin, 1, cin * 9, 9)
-                dpool, _ = ops.igemm3(dy, wd3, cin, B, Hh, Ww, co, flipped)
-            else:
-                wd = ops.pack_weight(cw, 9, co, cin, 1, cin * 9, 9)
-                dpool, _ = ops.igemm(dy, wd, cin, B, Hh, Ww, co, taps=flipped)
+        self._cnn_backward(ctx, d.view(B, T, 1, self.nb_filters[-1]))
 
     def forward(self, x):
         if torch.is_grad_enabled() and self.training:
