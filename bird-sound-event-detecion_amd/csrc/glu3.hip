@@ -684,8 +684,8 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
         }
       }
     } else {
-      // ph = 2: the partner row m + TW sits dr registers further (TW = 16 -> 8, TW = 8 -> 4, TW = 2 -> 2)
-      const int dr = TW == 16 ? 8 : (TW == 8 ? 4 : 2);
+      // ph = 2: the partner row m + TW sits dr registers further (TW = 16 -> 8, TW = 8 -> 4, TW = 2 -> 2, TW = 1 -> 1)
+      const int dr = TW == 16 ? 8 : (TW == 8 ? 4 : (TW == 2 ? 2 : 1));
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int mm = wave * 32 + crow3g(r, 0) + lhv;
@@ -701,7 +701,8 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
             float v;
             if (dr == 8) v = acc[j][r] + acc[j][(r + 8) & 15] + (P.pw == 2 ? acc[j][r | 1] + acc[j][((r + 8) & 15) | 1] : 0.f);
             else if (dr == 4) v = acc[j][r] + acc[j][(r + 4) & 15] + (P.pw == 2 ? acc[j][r | 1] + acc[j][((r + 4) & 15) | 1] : 0.f);
-            else v = acc[j][r] + acc[j][(r + 2) & 15] + (P.pw == 2 ? acc[j][r | 1] + acc[j][((r + 2) & 15) | 1] : 0.f);
+            else if (dr == 2) v = acc[j][r] + acc[j][(r + 2) & 15] + (P.pw == 2 ? acc[j][r | 1] + acc[j][((r + 2) & 15) | 1] : 0.f);
+            else v = acc[j][r] + acc[j][(r + 1) & 15];  // TW = 1 (width-1 maps of the FPN levels): pw = 1
             dst[32 * j] = v * inv_pool;
           }
         }
@@ -795,8 +796,8 @@ extern "C" int bsed_glu_fwd3(const float* y, const float* scale, const float* sh
   if (rc) return rc;
   BSED_CHECK_ARG(G > 0 && G <= P.ntiles, "bsed_glu_fwd3: G must be in 1..%d tiles", P.ntiles);
   BSED_CHECK_ARG(pw == 1 || TW >= 2, "bsed_glu_fwd3: horizontal pooling needs TW >= 2");
-  BSED_CHECK_ARG(ph == 1 || ((TW == 16 || TW == 8 || TW == 2) && TH % 2 == 0),
-                 "bsed_glu_fwd3: vertical pooling is lane-local only for TW in {2,8,16} (got %d)", TW);
+  BSED_CHECK_ARG(ph == 1 || ((TW == 16 || TW == 8 || TW == 2 || (TW == 1 && pw == 1)) && TH % 2 == 0),
+                 "bsed_glu_fwd3: vertical pooling is lane-local only for TW in {1,2,8,16} (got %d)", TW);
   P.y = y; P.scale = scale; P.shift = shift; P.w = w; P.bias = bias; P.dpool = nullptr;
   P.g = nullptr; P.part_dw = nullptr; P.part_db = nullptr; P.part_st = nullptr; P.pooled = pooled;
   P.drop_p = drop_p; P.rng_stream = rng_stream; P.seed = seed;

@@ -161,18 +161,25 @@ class CRNN(_FlatModule):
                        (f"rnn.rnn.weight_hh_l{l}", (3 * H, H)), (f"rnn.rnn.weight_hh_l{l}_reverse", (3 * H, H)),
                        (f"rnn.rnn.bias_ih_l{l}", (3 * H,)), (f"rnn.rnn.bias_ih_l{l}_reverse", (3 * H,)),
                        (f"rnn.rnn.bias_hh_l{l}", (3 * H,)), (f"rnn.rnn.bias_hh_l{l}_reverse", (3 * H,))]
-        self._build(pspecs, bspecs, device)
-        self.nbt = torch.zeros(len(nb_filters), device=device, dtype=torch.int64)
+        ep, eb, extra_bn = self._extra_specs()
+        self._build(pspecs + ep, bspecs + eb, device)
+        self.nbt = torch.zeros(len(nb_filters) + len(extra_bn), device=device, dtype=torch.int64)
         for i in range(len(nb_filters)):
             self.P(f"cnn.batchnorm{i}").register_buffer("num_batches_tracked", self.nbt[i])
+        for j, name in enumerate(extra_bn):
+            self.P(name).register_buffer("num_batches_tracked", self.nbt[len(nb_filters) + j])
         self.reset_parameters()
+
+    def _extra_specs(self):
+        """(parameter specs, buffer specs, names of extra BatchNorm modules) of a subclass"""
+        return [], [], []
 
     # ------------------------------------------------------------------ init / state
     @torch.no_grad()
     def reset_parameters(self):
         """PyTorch default init (what the reference modules have before weights_init is applied)."""
         for name, p in self.named_parameters():
-            if "batchnorm" in name:
+            if "batchnorm" in name or ".bn_" in name:
                 p.fill_(1.0 if name.endswith("weight") else 0.0)
             elif name.startswith("rnn"):
                 p.uniform_(-1 / math.sqrt(self.n_hidden), 1 / math.sqrt(self.n_hidden))
@@ -235,19 +242,20 @@ class CRNN(_FlatModule):
         glu-linear) parameter prefixes.  Returns (pooled, saved-for-backward dict)."""
         ph, pw = pool
         cw, cb = self.P(names[0] + ".weight"), self.P(names[0] + ".bias")
+        taps, wsrc, s_tap = self._conv_taps(cw, Ww)
         if first:
             y, stats = ops.conv0_fwd(a, cw, cb, B, Hh, Ww, co, want_stats=train)
         else:
             epi = ops.EPI_STATS if train else ops.EPI_PLAIN
             if self.conv_mode == "bf16x3" and cin % 32 == 0:
-                w3 = ops.pack_weight3(cw, 9, cin, co, 1, 9, cin * 9)
-                y, stats = ops.igemm3(a, w3, co, B, Hh, Ww, cin, ops.TAPS3x3, bias=cb, epilogue=epi)
+                w3 = ops.pack_weight3(wsrc, len(taps), cin, co, s_tap, 9, cin * 9)
+                y, stats = ops.igemm3(a, w3, co, B, Hh, Ww, cin, taps, bias=cb, epilogue=epi)
             elif self.conv_mode == "bf16x3" and cin == 16 and ops.igemm3s_supported(Ww, cin):
                 w3s = ops.pack_weight3s(cw, 9, co, 1, 9, cin * 9)
                 y, stats = ops.igemm3s(a, w3s, co, B, Hh, Ww, ops.TAPS3x3, bias=cb, epilogue=epi)
             else:
-                wpk = ops.pack_weight(cw, 9, cin, co, 1, 9, cin * 9)
-                y, stats = ops.igemm(a, wpk, co, B, Hh, Ww, cin, taps=ops.TAPS3x3, bias=cb, epilogue=epi)
+                wpk = ops.pack_weight(wsrc, len(taps), cin, co, s_tap, 9, cin * 9)
+                y, stats = ops.igemm(a, wpk, co, B, Hh, Ww, cin, taps=taps, bias=cb, epilogue=epi)
         bn = self.P(names[1])
         if train:
             mean, invstd, scale, shift = ops.bn_finalize(stats, co, float(B * Hh * Ww), BN_EPS, BN_MOMENTUM,
@@ -271,6 +279,14 @@ class CRNN(_FlatModule):
         blk = dict(inp=a, y=y, mean=mean, invstd=invstd, scale=scale, shift=shift, H=Hh, W=Ww, cin=cin, co=co,
                    pool=(ph, pw), names=names, drop=drop, rng=rng_stream, first=first)
         return pooled, blk
+
+    @staticmethod
+    def _conv_taps(cw, Ww):
+        """taps of a 3x3 / pad 1 convolution and how to find their weights.  On a width-1 map (the FPN levels) the six
+        taps with dw != 0 only ever see zero padding: the convolution is exactly its centre column, a 3x1 stencil."""
+        if Ww > 1:
+            return ops.TAPS3x3, cw, 1
+        return ((-1, 0), (0, 0), (1, 0)), cw.view(-1)[1:], 3   # weight[co][ci][kh][1]: element offset 1, tap stride 3
 
     def _gru_forward(self, seq, B, T, prefix, save):
         """2-layer BiGRU (reference src/models/RNN.py:7-16): input projections as one GEMM, then the recurrence"""
@@ -381,20 +397,22 @@ class CRNN(_FlatModule):
         ops.bn_bwd(st2, co, float(B * Hh * Ww), bn.weight, blk["mean"], blk["invstd"], bn.weight.grad,
                    bn.bias.grad, g, y)
         dy = g
-        part, G, KP, NP = ops.wgrad(blk["inp"], dy, B, Hh, Ww, cin, co, taps=ops.TAPS3x3)
-        ops.reduce_partials(part, G, 9, KP, NP, cin, co, cw.grad, 1, 9, cin * 9)
+        taps, wsrc, s_tap = self._conv_taps(cw, Ww)
+        part, G, KP, NP = ops.wgrad(blk["inp"], dy, B, Hh, Ww, cin, co, taps=taps)
+        ops.reduce_partials(part, G, len(taps), KP, NP, cin, co, cw.grad, s_tap, 9, cin * 9,
+                            dst_offset=0 if Ww > 1 else 1)
         if not need_dgrad:
             return None
-        flipped = [(-a, -b) for a, b in ops.TAPS3x3]
+        flipped = [(-a, -b) for a, b in taps]
         if self.conv_mode == "bf16x3" and co == 32 and cin <= 32 and ops.igemm3s_supported(Ww, co):
             # data gradient of a 32-channel layer: all taps' weights resident in LDS (csrc/igemm3.hip, igemm3s)
             wds = ops.pack_weight3s(cw, 9, cin, 1, cin * 9, 9, K=co)
             d_in, _ = ops.igemm3s(dy, wds, cin, B, Hh, Ww, flipped)
         elif self.conv_mode == "bf16x3":
-            wd3 = ops.pack_weight3(cw, 9, co, cin, 1, cin * 9, 9)
+            wd3 = ops.pack_weight3(wsrc, len(taps), co, cin, s_tap, cin * 9, 9)
             d_in, _ = ops.igemm3(dy, wd3, cin, B, Hh, Ww, co, flipped)
         else:
-            wd = ops.pack_weight(cw, 9, co, cin, 1, cin * 9, 9)
+            wd = ops.pack_weight(wsrc, len(taps), co, cin, s_tap, cin * 9, 9)
             d_in, _ = ops.igemm(dy, wd, cin, B, Hh, Ww, co, taps=flipped)
         return d_in
 
@@ -457,6 +475,129 @@ class CRNN(_FlatModule):
         else:
             enc, _ = self.run_forward(x, save=False)
         return enc, enc
+
+
+class CRNN_fpn(CRNN):
+    """Drop-in for the reference's feature-pyramid variant (src/models/CRNN_GRL.py:293-389 with
+    src/models/CNN_FPN.py:33-100; the ``-fpn`` flag of every training script).
+
+    On top of the seven CNN blocks, two more pyramid levels REUSE one conv3x3 / BatchNorm / GLU (``cnn.cnn_fcn``,
+    ``cnn.bn_fcn``, ``cnn.glu``), each followed by Dropout(0.5) -- fixed, not the constructor's dropout -- and
+    AvgPool((2,1)): T, T/2 and T/4 frames.  Three 2-layer BiGRUs (``rnn``, ``rnn_2``, ``rnn_4``) run on the three
+    levels; the coarse outputs are upsampled along time (bilinear, align_corners=True) and fused by two 1x1
+    convolutions over concatenated channels (``conv1x1_2``, ``conv1x1_4``).  The reference hard-codes the upsample
+    sizes (156 and 313 frames, i.e. 10 s at 32 kHz); here they follow the input length (T/2 and T), which is the same
+    thing for the reference's shapes.  ``cnn.conv1x1`` exists in the reference module but is never called; it is kept
+    because it owns state-dict entries (its gradient stays zero)."""
+
+    FPN_DROPOUT = 0.5
+
+    def _extra_specs(self):
+        H = self.n_hidden
+        ps = [("cnn.cnn_fcn.weight", (128, 128, 3, 3)), ("cnn.cnn_fcn.bias", (128,)),
+              ("cnn.glu.linear.weight", (128, 128)), ("cnn.glu.linear.bias", (128,)),
+              ("cnn.bn_fcn.weight", (128,)), ("cnn.bn_fcn.bias", (128,)),
+              ("cnn.conv1x1.weight", (128, 256, 1, 1)), ("cnn.conv1x1.bias", (128,))]
+        for pfx in ("rnn_2", "rnn_4"):
+            for l in range(2):
+                nin = self.nb_filters[-1] if l == 0 else 2 * H
+                ps += [(f"{pfx}.rnn.weight_ih_l{l}", (3 * H, nin)), (f"{pfx}.rnn.weight_ih_l{l}_reverse", (3 * H, nin)),
+                       (f"{pfx}.rnn.weight_hh_l{l}", (3 * H, H)), (f"{pfx}.rnn.weight_hh_l{l}_reverse", (3 * H, H)),
+                       (f"{pfx}.rnn.bias_ih_l{l}", (3 * H,)), (f"{pfx}.rnn.bias_ih_l{l}_reverse", (3 * H,)),
+                       (f"{pfx}.rnn.bias_hh_l{l}", (3 * H,)), (f"{pfx}.rnn.bias_hh_l{l}_reverse", (3 * H,))]
+        ps += [("conv1x1_2.weight", (256, 512, 1, 1)), ("conv1x1_2.bias", (256,)),
+               ("conv1x1_4.weight", (256, 512, 1, 1)), ("conv1x1_4.bias", (256,))]
+        bs = [("cnn.bn_fcn.running_mean", (128,)), ("cnn.bn_fcn.running_var", (128,))]
+        return ps, bs, ["cnn.bn_fcn"]
+
+    # 1x1 convolution over channels of a (B,T,512) sequence == GEMM with the (256,512) weight
+    def _fuse(self, cat, name, B, T):
+        w, b = self.P(name + ".weight"), self.P(name + ".bias")
+        if self.conv_mode == "bf16x3":
+            w3 = ops.pack_weight3(w, 1, 512, 256, 0, 1, 512)
+            out, _ = ops.igemm3(cat, w3, 256, 1, B * T, 1, 512, ((0, 0),), bias=b)
+        else:
+            wpk = ops.pack_weight(w, 1, 512, 256, 0, 1, 512)
+            out, _ = ops.igemm(cat, wpk, 256, 1, B * T, 1, 512, bias=b)
+        return out.view(B, T, 256)
+
+    def _fuse_backward(self, cat, d_out, name, B, T):
+        """accumulates dW, db of the 1x1 convolution; returns dL/d(cat) (B,T,512)"""
+        w, b = self.P(name + ".weight"), self.P(name + ".bias")
+        ops.colsum(d_out, B * T, 256, 256, b.grad)
+        part, G, KP, NP = ops.wgrad(cat, d_out, 1, B * T, 1, 512, 256)
+        ops.reduce_partials(part, G, 1, KP, NP, 512, 256, w.grad, 0, 1, 512)
+        if self.conv_mode == "bf16x3":
+            w3 = ops.pack_weight3(w, 1, 256, 512, 0, 512, 1)
+            d_cat, _ = ops.igemm3(d_out, w3, 512, 1, B * T, 1, 256, ((0, 0),))
+        else:
+            wpk = ops.pack_weight(w, 1, 256, 512, 0, 512, 1)
+            d_cat, _ = ops.igemm(d_out, wpk, 512, 1, B * T, 1, 256)
+        return d_cat.view(B, T, 512)
+
+    def run_forward(self, x, save=True):
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise L.BsedError(f"CRNN_fpn expects (B,1,T,F), got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        B = x.shape[0]
+        train = self.training
+        drop = self.dropout_p if train else 0.0
+        dropf = self.FPN_DROPOUT if train else 0.0
+        ctx = {"B": B, "blocks": [], "train": train, "seed": self.seed, "x": x} if save else None
+        a, T = self._cnn_forward(x, ctx)
+        T2, T4 = T // 2, (T // 2) // 2
+        if T4 < 1:
+            raise L.BsedError(f"CRNN_fpn needs at least 4 CNN output frames, got {T}")
+        C = self.nb_filters[-1]
+        names = ("cnn.cnn_fcn", "cnn.bn_fcn", "cnn.glu.linear")
+        nbt = self.nbt[len(self.nb_filters):len(self.nb_filters) + 1]
+        x2, blk2 = self._block_forward(a, B, T, 1, C, C, (2, 1), names, dropf, 300, nbt, train)
+        x4, blk4 = self._block_forward(x2, B, T2, 1, C, C, (2, 1), names, dropf, 301, nbt, train)
+        levels = []
+        for seq, Tl, pfx, stream in ((a, T, "rnn", 200), (x2, T2, "rnn_2", 201), (x4, T4, "rnn_4", 202)):
+            out, layers = self._gru_forward(seq.view(B, Tl, C), B, Tl, pfx, save)
+            if drop > 0:
+                out = ops.dropout(out, drop, stream, self.seed)
+            levels.append((out, layers))
+        g1, g2, g4 = (lv[0] for lv in levels)
+        dev = x.device
+        cat2 = torch.empty((B, T2, 512), device=dev, dtype=torch.float32)
+        cat2[:, :, :256].copy_(g2)
+        ops.upsample_time(g4, T2, out=cat2, out_offset=256)
+        f2 = self._fuse(cat2, "conv1x1_2", B, T2)
+        cat1 = torch.empty((B, T, 512), device=dev, dtype=torch.float32)
+        cat1[:, :, :256].copy_(g1)
+        ops.upsample_time(f2, T, out=cat1, out_offset=256)
+        enc = self._fuse(cat1, "conv1x1_4", B, T)
+        if save:
+            ctx.update(T=T, T2=T2, T4=T4, drop=drop, fpn_blocks=(blk2, blk4), gru=[lv[1] for lv in levels],
+                       cat1=cat1, cat2=cat2)
+        return enc, ctx
+
+    def run_backward(self, ctx, d_enc):
+        B, T, T2, T4 = ctx["B"], ctx["T"], ctx["T2"], ctx["T4"]
+        seed, drop = ctx["seed"], ctx["drop"]
+        C = self.nb_filters[-1]
+        d_cat1 = self._fuse_backward(ctx["cat1"], d_enc.contiguous(), "conv1x1_4", B, T)
+        d_g1 = d_cat1[:, :, :256].contiguous()
+        d_f2 = ops.upsample_time_bwd(d_cat1, T2, 256, in_offset=256)
+        d_cat2 = self._fuse_backward(ctx["cat2"], d_f2, "conv1x1_2", B, T2)
+        d_g2 = d_cat2[:, :, :256].contiguous()
+        d_g4 = ops.upsample_time_bwd(d_cat2, T4, 256, in_offset=256)
+        d_seq = []
+        for d, Tl, pfx, stream, layers in ((d_g1, T, "rnn", 200, ctx["gru"][0]), (d_g2, T2, "rnn_2", 201, ctx["gru"][1]),
+                                           (d_g4, T4, "rnn_4", 202, ctx["gru"][2])):
+            if drop > 0:
+                d = ops.dropout(d, drop, stream, seed)
+            d_seq.append(self._gru_backward(layers, d, B, Tl, pfx))
+        if not self.train_cnn:
+            return
+        blk2, blk4 = ctx["fpn_blocks"]
+        d_x2 = self._block_backward(blk4, d_seq[2].view(B, T4, 1, C), B, seed)          # dL/d x_2 through level 4
+        ops.axpy(d_x2.view(-1), d_seq[1].reshape(-1))                                    # + through rnn_2
+        d_a = self._block_backward(blk2, d_x2.view(B, T2, 1, C), B, seed)                # dL/d a through level 2
+        ops.axpy(d_a.view(-1), d_seq[0].reshape(-1))                                     # + through rnn
+        self._cnn_backward(ctx, d_a.view(B, T, 1, C))
 
 
 class _CRNNFunction(torch.autograd.Function):

@@ -357,7 +357,8 @@ def glu_bwd_fused(y, scale, shift, wfwd, w, bias, dpool, B, H, W, C, pool, drop_
 
 def glu_fwd3_supported(W, C, pool):
     TH, TW = tile_for(W)
-    return C in (32, 64, 128) and (pool[1] == 1 or TW >= 2) and (pool[0] == 1 or (TW in (2, 8, 16) and TH % 2 == 0))
+    return (C in (32, 64, 128) and (pool[1] == 1 or TW >= 2) and
+            (pool[0] == 1 or ((TW in (2, 8, 16) or (TW == 1 and pool[1] == 1)) and TH % 2 == 0)))
 
 
 def glu_fwd3(y, scale, shift, w, bias, B, H, W, C, pool, drop_p, rng_stream, seed):
@@ -575,3 +576,23 @@ def ema_update(ema, p, alpha):
 def ema_update_i64(ema, p, alpha):
     L.call("bsed_ema_update_i64", L.ptr(ema, torch.int64), L.ptr(p, torch.int64), _i(p.numel()),
            ctypes.c_float(alpha), L.stream())
+
+
+def upsample_time(inp, T_out, out=None, out_offset=0):
+    """(B,T_in,C) -> (B,T_out,C) linear interpolation along time (align_corners=True); ``out`` may be a wider
+    (B,T_out,P) buffer whose columns out_offset..out_offset+C receive the result (concatenation without a copy)"""
+    B, T_in, C = inp.shape
+    if out is None:
+        out = torch.empty((B, T_out, C), device=inp.device, dtype=torch.float32)
+    L.call("bsed_upsample_time_fwd", L.ptr(inp), _fp(_dp(out, out_offset)), _i(B), _i(T_in), _i(T_out), _i(C),
+           _i(inp.shape[2]), _i(out.shape[2]), L.stream())
+    return out
+
+
+def upsample_time_bwd(dout, T_in, C, in_offset=0):
+    """adjoint of upsample_time: dout (B,T_out,P) columns in_offset..in_offset+C -> (B,T_in,C)"""
+    B, T_out, P = dout.shape
+    din = torch.empty((B, T_in, C), device=dout.device, dtype=torch.float32)
+    L.call("bsed_upsample_time_bwd", _fp(_dp(dout, in_offset)), L.ptr(din), _i(B), _i(T_in), _i(T_out), _i(C), _i(P),
+           _i(C), L.stream())
+    return din

@@ -266,6 +266,16 @@ int bsed_disc_head(const float* y5, const float* scale, const float* shift, cons
                    float* dbl_part, float* loss_part, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Feature-pyramid glue of CRNN_fpn (csrc/fpn.hip); replaces nn.Upsample((T_out,1), mode='bilinear',
+ * align_corners=True) on width-1 maps (src/models/CRNN_GRL.py:333-336,378-384) and its backward.
+ * Tensors are (B, T, C) with a row pitch, so the output can be the right half of a concatenation buffer.
+ * ---------------------------------------------------------------------------------------------- */
+int bsed_upsample_time_fwd(const float* in, float* out, int B, int T_in, int T_out, int C, int in_pitch, int out_pitch,
+                           void* stream);
+int bsed_upsample_time_bwd(const float* dout, float* din, int B, int T_in, int T_out, int C, int dout_pitch,
+                           int din_pitch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Bidirectional GRU recurrence (csrc/gru.hip); replaces nn.GRU of src/models/RNN.py:7-16.
  *   xp    (B,T,768)  x @ [W_ih; W_ih_reverse]^T + b_ih   (from bsed_igemm), [dir*384 + gate*128 + k]
  *   w_hh  (2,384,128), b_hh (2,384)                       gate order r,z,n

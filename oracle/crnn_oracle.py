@@ -108,6 +108,64 @@ class CRNN(nn.Module):
         return x, x
 
 
+class CNN_FPN(nn.Module):
+    """reference src/models/CNN_FPN.py:33-100: the CNN plus two more pyramid levels that REUSE one conv / BatchNorm /
+    GLU (cnn_fcn, bn_fcn, glu), each followed by Dropout(0.5) -- a fixed 0.5, not the constructor's dropout -- and
+    AvgPool((2,1)).  deconv1/deconv2/conv1x1 exist in the reference module but its forward never calls them; conv1x1
+    is kept because it owns state-dict entries."""
+
+    def __init__(self, n_in_channel, activation="Relu", conv_dropout=0, kernel_size=(3, 3, 3), padding=(1, 1, 1),
+                 stride=(1, 1, 1), nb_filters=(64, 64, 64), pooling=((1, 4), (1, 4), (1, 4))):
+        super().__init__()
+        self.nb_filters = list(nb_filters)
+        self.cnn = CNN(n_in_channel, activation, conv_dropout, kernel_size, padding, stride, nb_filters, pooling).cnn
+        self.cnn_fcn = nn.Conv2d(128, 128, 3, 1, 1)
+        self.glu = GLU(128)
+        self.pool_fcn = nn.AvgPool2d([2, 1])
+        self.bn_fcn = nn.BatchNorm2d(128, eps=0.001, momentum=0.99)
+        self.conv1x1 = nn.Conv2d(256, 128, 1)
+        self.dropout = nn.Dropout(0.5)
+
+    def level(self, x):
+        return self.pool_fcn(self.dropout(self.glu(self.bn_fcn(self.cnn_fcn(x)))))
+
+    def forward(self, x):
+        x = self.cnn(x)
+        x_2 = self.level(x)
+        x_4 = self.level(x_2)
+        return x, x_2, x_4
+
+
+class CRNN_fpn(nn.Module):
+    """reference src/models/CRNN_GRL.py:293-389: three BiGRUs on the 313 / 156 / 78 frame levels, coarse levels
+    upsampled (bilinear, align_corners=True, hard-coded (156,1) and (313,1)) and fused by 1x1 convolutions"""
+
+    def __init__(self, n_in_channel, nclass, attention=False, activation="Relu", dropout=0, train_cnn=True,
+                 rnn_type="BGRU", n_RNN_cell=64, n_layers_RNN=1, dropout_recurrent=0, cnn_integration=False, **kwargs):
+        super().__init__()
+        self.cnn = CNN_FPN(n_in_channel, activation, dropout, **kwargs)
+        nb_in = self.cnn.nb_filters[-1]
+        self.rnn = BidirectionalGRU(nb_in, n_RNN_cell, dropout=dropout_recurrent, num_layers=n_layers_RNN)
+        self.rnn_2 = BidirectionalGRU(nb_in, n_RNN_cell, dropout=dropout_recurrent, num_layers=n_layers_RNN)
+        self.rnn_4 = BidirectionalGRU(nb_in, n_RNN_cell, dropout=dropout_recurrent, num_layers=n_layers_RNN)
+        self.dropout = nn.Dropout(dropout)
+        self.upsample_2 = nn.Upsample((313, 1), mode="bilinear", align_corners=True)
+        self.upsample_4 = nn.Upsample((156, 1), mode="bilinear", align_corners=True)
+        self.conv1x1_2 = nn.Conv2d(512, 256, 1)
+        self.conv1x1_4 = nn.Conv2d(512, 256, 1)
+
+    def forward(self, x):
+        x, x_2, x_4 = self.cnn(x)
+        seq = lambda v: v.squeeze(-1).permute(0, 2, 1)               # (B,C,T,1) -> (B,T,C)
+        img = lambda v: v.permute(0, 2, 1).unsqueeze(-1)             # (B,T,C) -> (B,C,T,1)
+        x = img(self.dropout(self.rnn(seq(x))))
+        x_2 = img(self.dropout(self.rnn_2(seq(x_2))))
+        x_4 = img(self.dropout(self.rnn_4(seq(x_4))))
+        x_2 = self.conv1x1_2(torch.cat((x_2, self.upsample_4(x_4)), 1))
+        x = self.conv1x1_4(torch.cat((x, self.upsample_2(x_2)), 1)).squeeze(-1).permute(0, 2, 1)
+        return x, x
+
+
 class Predictor(nn.Module):
     def __init__(self, nclass, attention=False, n_RNN_cell=64, **kwargs):
         super().__init__()

@@ -282,6 +282,45 @@ def labels_case():
     print("wrote labels_kat.json")
 
 
+def fpn_case():
+    """CRNN_fpn of the reference (CRNN_GRL.py:293-389) at the only length its hard-coded Upsample sizes admit:
+    1255 input frames -> 313 / 156 / 78.  Train-mode vectors are taken with BOTH dropouts off (the FPN levels carry a
+    fixed Dropout(0.5): its p is set to 0 on the instance) so that gradients are comparable."""
+    from models.CRNN_GRL import CRNN_fpn as RefFPN
+    B, T, seed = 2, 1255, 31
+    g = {"meta": np.array([B, T, seed], dtype=np.int64)}
+    x = seeded.db_like_input(seed + 10, B, T)
+    kw = dict(CRNN_KWARGS)
+    kw["dropout"] = 0.5
+    m = RefFPN(**kw)
+    vals = seeded.load_seeded(m, seed)
+    g["weight_checksum"] = np.array([seeded.checksum(vals)])
+    g["state_names"] = np.array(list(m.state_dict().keys()))
+    m.eval()
+    with torch.no_grad():
+        enc, d_in = m(t(x))
+    g["eval_enc"] = enc.numpy()
+    kw["dropout"] = 0.0
+    m = RefFPN(**kw)
+    seeded.load_seeded(m, seed)
+    m.cnn.dropout.p = 0.0
+    m.train()
+    enc, _ = m(t(x))
+    w = torch.sin(torch.arange(enc.numel(), dtype=torch.float32)).view_as(enc) * 1e-2
+    (enc * w).sum().backward()
+    g["train_enc"] = enc.detach().numpy()
+    grads = {k: p.grad.detach().numpy().copy() for k, p in m.named_parameters() if p.grad is not None}
+    g["grad_names"] = np.array(list(grads.keys()))
+    g["grad_norms"] = np.array([float(np.linalg.norm(v.astype(np.float64))) for v in grads.values()])
+    for k, v in small_tensors(grads).items():
+        g["grad/" + k] = v
+    sd = m.state_dict()
+    for k in ("cnn.bn_fcn.running_mean", "cnn.bn_fcn.running_var", "cnn.bn_fcn.num_batches_tracked"):
+        g["after/" + k] = sd[k].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "crnn_fpn.npz"), **g)
+    print("wrote crnn_fpn.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in list(g.items())[:6]})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -291,3 +330,4 @@ if __name__ == "__main__":
     clipd_case()
     crnn_case("small", B=2, T=64, seed=11, adam_steps=3, mt=True)
     crnn_case("R", B=2, T=1255, seed=23, adam_steps=1, mt=False)
+    fpn_case()

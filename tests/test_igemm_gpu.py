@@ -211,7 +211,7 @@ def test_glu_backward_split_fp32_matches_fp32_fused_kernel(C, B, H, W, pool):
 @pytest.mark.parametrize("C,B,H,W,pool", [(32, 2, 24, 64, (2, 2)), (32, 1, 13, 16, (2, 2)), (32, 2, 627, 64, (2, 2)),
                                           (64, 2, 27, 32, (1, 2)), (64, 1, 17, 8, (2, 2)), (128, 2, 21, 16, (1, 2)),
                                           (128, 3, 9, 2, (1, 2)), (128, 1, 40, 4, (1, 2)), (64, 2, 10, 2, (2, 2)),
-                                          (128, 1, 12, 8, (1, 1))])
+                                          (128, 1, 12, 8, (1, 1)), (128, 2, 313, 1, (2, 1)), (128, 3, 156, 1, (2, 1))])
 def test_glu_forward_split_fp32_matches_torch(C, B, H, W, pool):
     """csrc/glu3.hip forward vs torch (dropout off) and vs the fp32-core kernel (dropout on: same masks)"""
     from bsed_amd import ops

@@ -217,3 +217,37 @@ def test_mel_sinusoid_silence_and_clamp():
     clean, noisy = mo.transform_pair(mo.preprocess(y2), 130, unit_noise=np.zeros((126, 128)))
     assert clean.shape == (1, 130, 128) and np.all(clean[0, 126:] == 0)
     np.testing.assert_allclose(clean, noisy, atol=1e-4)
+
+
+def test_oracle_crnn_fpn_matches_reference_golden(golden_dir):
+    """oracle.crnn_oracle.CRNN_fpn (restatement of src/models/CRNN_GRL.py:293-389 + CNN_FPN.py:33-100) against the
+    vectors the reference's own CRNN_fpn produced: same state-dict entries, eval and train forward, gradient norms"""
+    import os
+    import numpy as np
+    import torch
+    from oracle import crnn_oracle as co, seeded
+    g = np.load(os.path.join(golden_dir, "crnn_fpn.npz"))
+    B, T, seed = (int(v) for v in g["meta"])
+    kw = dict(co.CRNN_KWARGS)
+    kw["dropout"] = 0.5
+    m = co.CRNN_fpn(**kw)
+    assert list(m.state_dict().keys()) == [str(n) for n in g["state_names"]]
+    vals = seeded.load_seeded(m, seed)
+    assert abs(seeded.checksum(vals) - float(g["weight_checksum"][0])) < 1e-6 * float(g["weight_checksum"][0])
+    x = torch.from_numpy(seeded.db_like_input(seed + 10, B, T))
+    m.eval()
+    with torch.no_grad():
+        enc, _ = m(x)
+    np.testing.assert_allclose(enc.numpy(), g["eval_enc"], atol=1e-6)
+    kw["dropout"] = 0.0
+    m = co.CRNN_fpn(**kw)
+    seeded.load_seeded(m, seed)
+    m.cnn.dropout.p = 0.0
+    m.train()
+    enc, _ = m(x)
+    np.testing.assert_allclose(enc.detach().numpy(), g["train_enc"], atol=1e-5)
+    w = torch.sin(torch.arange(enc.numel(), dtype=torch.float32)).view_as(enc) * 1e-2
+    (enc * w).sum().backward()
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    for n, ref_norm in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(float(grads[str(n)].double().norm()) - ref_norm) < 1e-4 * ref_norm + 1e-9, str(n)
