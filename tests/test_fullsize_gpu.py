@@ -122,3 +122,29 @@ def test_train_step_is_bitwise_repeatable_at_full_size():
         del junk
     for rep in (1, 2):
         assert torch.equal(grads[0][0], grads[rep][0]) and torch.equal(grads[0][1], grads[rep][1])
+
+
+@pytest.mark.parametrize("Bq,Tq,Fq,seed", [(1, 64, 128, 1), (3, 100, 128, 2), (5, 260, 128, 3), (2, 1255, 128, 4), (7, 36, 128, 5)])
+def test_split_fp32_and_fp32_modes_agree_on_odd_shapes(Bq, Tq, Fq, seed):
+    """the two contraction modes are independent kernel families (bf16 cores with split operands vs fp32 cores):
+    their forward outputs and every gradient tensor must agree on shapes with partial tiles, odd pooled extents and
+    batch sizes that leave idle rows in the recurrence workgroups.  Dropout on (same masks by construction)."""
+    outs = []
+    x = torch.from_numpy(seeded.db_like_input(20 + seed, Bq, Tq, Fq)).cuda()
+    for mode in ("bf16x3", "fp32"):
+        crnn, _ = _models(0.5, seed=seed)
+        crnn.conv_mode = mode
+        crnn.train(); crnn.set_seed(3)
+        enc, ctx = crnn.run_forward(x, save=True)
+        d = (torch.cos(torch.arange(enc.numel(), device="cuda", dtype=torch.float32)).view_as(enc) * 1e-2)
+        crnn.zero_grad(); crnn._attach_grads()
+        crnn.run_backward(ctx, d)
+        outs.append((enc.clone(), {k: p.grad.clone() for k, p in crnn.named_parameters()}))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-4
+    bad = []
+    for k in outs[0][1]:
+        a, b = outs[0][1][k], outs[1][1][k]
+        err = float((a - b).norm() / (b.norm() + 1e-12))
+        if err > 3e-4 and float(b.norm()) > 1e-7:
+            bad.append((k, err))
+    assert not bad, bad
