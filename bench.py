@@ -163,6 +163,7 @@ def main():
     # The warm-up runs with a throw-away kernel timer: the first few hundred HIP events of a process make the runtime
     # grow its signal pool (a one-time ~45 ms stall, measured on a fresh box), which must not land in the timed region.
     if use_timer:
+        ops.KernelTimer.prime(2 * 120 * (args.steps + args.warmup) + 512)
         ops.set_timer(ops.KernelTimer())
     for i in range(args.warmup):
         step()

@@ -49,6 +49,17 @@ class KernelTimer:
     def __init__(self):
         self.records = {}  # key -> [flops_per_launch, [(start, end), ...], algorithmic_bytes_per_launch]
 
+    @staticmethod
+    def prime(n=4096):
+        """Create, record and retire n timing events once: the runtime grows its signal pool in steps that stall the
+        stream for tens of milliseconds the first time a process holds a few hundred events (measured ~45 ms on a
+        fresh MI355X box); doing it here keeps that out of whatever is timed later."""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        for e in evs:
+            e.record()
+        torch.cuda.synchronize()
+        del evs
+
     def launch(self, key, flops, fn, nbytes):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
