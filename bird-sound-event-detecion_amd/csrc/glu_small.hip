@@ -1,21 +1,30 @@
-// GLU stage of the FIRST CNN block (C = 16 channels on the full 865..1255 x 128 map) as pure streaming kernels.
-//
-// At C = 16 the per-position contraction is 16x16 = 256 MACs against 64 bytes of activation: 4 FLOP/B, far below
-// the MFMA ridge, and the block owns the largest tensor of the network (1.8 GB at B = 256).  The MFMA tile
-// kernel spends its time in per-tile overhead there, so this block gets dedicated HBM-bound kernels:
-//   * 4 lanes per position, one float4 (4 channels) each -> perfectly coalesced 16 B/lane loads and stores;
-//   * the 16-vector is all-gathered inside the 4-lane group with 3 xor-shuffles, the 16x16 weights sit in
-//     registers pre-permuted to the shuffle order (no dynamic register indexing);
+// GLU stage of the FIRST CNN block (C = 16 channels on the full 865..1255 x 128 map), the largest tensor of the
+// network (1.8 GB at B = 256), as streaming kernels: one float4 (4 channels) per lane, 16 B coalesced loads/stores.
 //   * forward:  y -> BN-apply -> Linear -> sigmoid gate -> dropout -> 2x2 avg-pool (vertical in registers,
 //               horizontal by one shuffle) -> pooled                 [reference src/models/CNN.py:5-16,59-67]
 //   * backward: y, d_pooled -> g = dL/d(BN output) written once, plus per-workgroup partials of dW_glu, db_glu and
-//               the two BatchNorm-backward sums (sum g, sum g*y) -- one read of y, one write of g.
+//               the two BatchNorm-backward sums (sum g, sum g*y) -- ONE pass: one read of y, one write of g.
+// The per-position 16x16 contractions run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32) thanks to the
+// lane map described below; the first version did them as register matvecs with shuffles and was VALU-bound
+// (0.68 + 2.23 ms per step at B = 256; now 0.48 + 0.97).
 #include "bsed_common.h"
 #include "../../include/bsed.h"
 #include <algorithm>
 
 #define GS_THREADS 512
 #define GS_C 16
+
+// Lane map of both kernels: lane = 16*q + p, p = one of the wave's 16 consecutive columns, q = channel quarter
+// (channels 4q..4q+3, one float4).  A wave's float4 load then covers 16 positions x 64 B = 1 KB contiguous, and -- the
+// point of the map -- the per-position 16x16 contractions run on the fp32 matrix cores without a single shuffle:
+//   lin^T[n][pos] = sum_c W[n][c] xn[pos][c]   as v_mfma_f32_16x16x4_f32 with A[i = n][k] = W[n][4q + kk] (per-lane
+//   constants), B[k][j = pos] = xn[pos][4q + kk] (the lane's own float4), and the D fragment (column = pos = lane&15,
+//   rows 4*(lane>>4) + r) is lin of the lane's own position and own four channels;
+//   g^T[c][pos]  = sum_n W[n][c] d_lin[pos][n] likewise with A[i = c][k] = W[4q + kk][c], accumulated onto the gate term.
+// Exact fp32 (these are the fp32 cores: no operand splitting).  The matrix pipe runs beside the VALU, which was the
+// bottleneck of the previous register-matvec version (64 + 64 FMAs and 24 shuffles per lane and position); with the
+// 64 weight registers gone the weight-gradient outer products fit in the same kernel: ONE backward pass over y.
+__device__ float g16_sink[256];
 
 struct f4 { float v[4]; };
 
@@ -26,20 +35,28 @@ __device__ __forceinline__ f4 shfl_xor4(const f4& a, int s) {
   return r;
 }
 
+// c += A(16 x 16 per-lane constants a[kk]) * B(16 positions x 16 channels, lane's own b[kk]); operands written by VALU
+// code just before are padded away from the MFMAs (see acc_handoff_fence in glu3.hip for the hazard this avoids)
+__device__ __forceinline__ f32x4 mm16(const float (&a)[4], float b0, float b1, float b2, float b3, f32x4 c) {
+  asm volatile("s_nop 4" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(c));
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b0, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b1, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b2, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b3, c, 0, 0, 0);
+  return c;
+}
+
 __global__ __launch_bounds__(GS_THREADS) void glu16_fwd_kernel(
     const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ wg, const float* __restrict__ bg, float* __restrict__ out, int B, int H, int W, int ph,
     int pw, float drop_p, uint32_t rng_stream, uint64_t seed) {
   constexpr int C = GS_C;
-  const int tid = threadIdx.x, q = tid & 3, col = tid >> 2;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
+  const int col = wave * 16 + p;
   const int Hp = H / ph, Wp = W / pw;
-  float wp[4][4][4];  // [shuffle step s][own channel i][kk] = W[4q+i][4(q^s)+kk]
+  float a1[4];  // W[n = p][4q + kk]
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) wp[s][i][kk] = wg[(4 * q + i) * C + 4 * (q ^ s) + kk];
+  for (int kk = 0; kk < 4; ++kk) a1[kk] = wg[p * C + 4 * q + kk];
   float sc[4], sh[4], bi[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { sc[i] = scale[4 * q + i]; sh[i] = shift[4 * q + i]; bi[i] = bg[4 * q + i]; }
@@ -52,34 +69,24 @@ __global__ __launch_bounds__(GS_THREADS) void glu16_fwd_kernel(
     for (int w0 = 0; w0 < W; w0 += GS_THREADS / 4) {
       const int w = w0 + col;
       const bool ok = w < W;
+      const int wc = ok ? w : W - 1;  // clamped: the matrix instructions need every lane, idle columns are masked
       float pooled[4] = {0.f, 0.f, 0.f, 0.f};
       for (int dh = 0; dh < ph; ++dh) {
         const int h = hp * ph + dh;
-        const size_t pos = ((size_t)b * H + h) * W + w;
-        f4 xn;
-        if (ok) {
-          const float4 v = *reinterpret_cast<const float4*>(y + pos * C + 4 * q);
-          xn.v[0] = fmaf(v.x, sc[0], sh[0]); xn.v[1] = fmaf(v.y, sc[1], sh[1]);
-          xn.v[2] = fmaf(v.z, sc[2], sh[2]); xn.v[3] = fmaf(v.w, sc[3], sh[3]);
-        } else {
-          xn.v[0] = xn.v[1] = xn.v[2] = xn.v[3] = 0.f;
-        }
-        float lin[4] = {bi[0], bi[1], bi[2], bi[3]};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const f4 o = s == 0 ? xn : shfl_xor4(xn, s);
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) lin[i] = fmaf(wp[s][i][kk], o.v[kk], lin[i]);
-        }
+        const size_t pos = ((size_t)b * H + h) * W + wc;
+        const float4 v = *reinterpret_cast<const float4*>(y + pos * C + 4 * q);
+        const float xn0 = fmaf(v.x, sc[0], sh[0]), xn1 = fmaf(v.y, sc[1], sh[1]);
+        const float xn2 = fmaf(v.z, sc[2], sh[2]), xn3 = fmaf(v.w, sc[3], sh[3]);
+        const f32x4 lin = mm16(a1, xn0, xn1, xn2, xn3, f32x4{0.f, 0.f, 0.f, 0.f});
+        const float xn[4] = {xn0, xn1, xn2, xn3};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          pooled[i] += lin[i] * sigmoid_fast(xn.v[i]) * drop_mul((uint64_t)pos * C + 4 * q + i, dkey, dthr, dscale);
+          pooled[i] += (lin[i] + bi[i]) * sigmoid_fast(xn[i]) *
+                       drop_mul((uint64_t)pos * C + 4 * q + i, dkey, dthr, dscale);
       }
       if (pw == 2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pooled[i] += __shfl_xor(pooled[i], 4, 64);
+        for (int i = 0; i < 4; ++i) pooled[i] += __shfl_xor(pooled[i], 1, 64);  // the neighbouring column
       }
       if (ok && (w & (pw - 1)) == 0 && (w / pw) < Wp) {
         float4 o = make_float4(pooled[0] * inv, pooled[1] * inv, pooled[2] * inv, pooled[3] * inv);
@@ -89,33 +96,24 @@ __global__ __launch_bounds__(GS_THREADS) void glu16_fwd_kernel(
   }
 }
 
-// MODE 0: g, db and the BN-backward sums (weights in registers, no dW accumulators)
-// MODE 1: dW_glu only (64 accumulators, no weights) -- two passes keep both under 128 VGPRs with 4 waves/SIMD
-// resident instead of one 256-VGPR kernel that spills and leaves HBM latency exposed.
-template <int MODE>
-__global__ __launch_bounds__(GS_THREADS) void glu16_bwd_kernel(
+#define GB16_THREADS 256
+// One pass: g, db, the BatchNorm-backward sums AND dW_glu.
+// (256 threads: at ~160 VGPRs three 4-wave workgroups fit per CU, one 8-wave workgroup would leave 2 waves per SIMD)
+__global__ __launch_bounds__(GB16_THREADS, 3) void glu16_bwd_kernel(
     const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ wg, const float* __restrict__ bg, const float* __restrict__ dpool,
     float* __restrict__ g_out, float* __restrict__ part_dw /*(G,C,C)*/, float* __restrict__ part_db /*(G,2,C)*/,
     float* __restrict__ part_st /*(G,2,C)*/, int B, int H, int W, int ph, int pw, float drop_p, uint32_t rng_stream,
     uint64_t seed) {
   constexpr int C = GS_C;
-  __shared__ float red[GS_THREADS * 17];
-  const int tid = threadIdx.x, q = tid & 3, col = tid >> 2;
+  __shared__ float red[GB16_THREADS * 17];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
+  const int col = wave * 16 + p;
   const int Hp = H / ph, Wp = W / pw;
   const int sph = ph >> 1, spw = pw >> 1;
-  // wp[s][i][kk] = W[4q+i][4(q^s)+kk].  It serves BOTH contractions: lin of the own channels (rows of W against the
-  // all-gathered x) and g = d_lin W (own d_lin rows against all 16 columns, then a reduce-scatter inside the 4-lane
-  // group), so the transposed copy of W never has to live in registers.
-  float wp[4][4][4];
-  if (MODE == 0) {
+  float a1[4], a2[4];  // W[n = p][4q + kk]  and  W[4q + kk][c = p]
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) wp[s][i][kk] = wg[(4 * q + i) * C + 4 * (q ^ s) + kk];
-  }
+  for (int kk = 0; kk < 4; ++kk) { a1[kk] = wg[p * C + 4 * q + kk]; a2[kk] = wg[(4 * q + kk) * C + p]; }
   float sc[4], sh[4], bi[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { sc[i] = scale[4 * q + i]; sh[i] = shift[4 * q + i]; bi[i] = bg[4 * q + i]; }
@@ -123,7 +121,7 @@ __global__ __launch_bounds__(GS_THREADS) void glu16_bwd_kernel(
   const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
   const float inv = 1.0f / (float)(ph * pw);
 
-  float dwa[4][4][4];  // dW[4q+i][4(q^s)+kk]
+  float dwa[4][4][4];  // dW[4q+i][4(q^s)+kk]: own d_lin rows against the quarter held by lane ^ 16s
   float dba[4] = {0.f, 0.f, 0.f, 0.f}, sga[4] = {0.f, 0.f, 0.f, 0.f}, sgya[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < 4; ++s)
@@ -132,28 +130,22 @@ __global__ __launch_bounds__(GS_THREADS) void glu16_bwd_kernel(
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) dwa[s][i][kk] = 0.f;
 
-  // flattened work list: (row of one clip, 128-column chunk); the next item's loads are issued before the
-  // current item's arithmetic so HBM latency overlaps the shuffle/FMA chain
-  const int chunks = (W + GS_THREADS / 4 - 1) / (GS_THREADS / 4);
+  // flattened work list: (row of one clip, 128-column chunk); the next item's loads are issued before the current
+  // item's arithmetic
+  const int chunks = (W + GB16_THREADS / 4 - 1) / (GB16_THREADS / 4);
   const int nitems = B * H * chunks;  // < 2^31 (checked on the host)
   float4 ny = make_float4(0.f, 0.f, 0.f, 0.f), nd = make_float4(0.f, 0.f, 0.f, 0.f);
   auto fetch = [&](int item) {
-    ny = make_float4(0.f, 0.f, 0.f, 0.f);
-    nd = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (item < nitems) {
-      const int ch = item % chunks;
-      const int row = item / chunks;
-      const int h = row % H;
-      const int b = row / H;
-      const int w = ch * (GS_THREADS / 4) + col;
-      if (w < W) {
-        const size_t pos = ((size_t)b * H + h) * W + w;
-        ny = *reinterpret_cast<const float4*>(y + pos * C + 4 * q);
-        const int hp = h >> sph, wpi = w >> spw;
-        if (hp < Hp && wpi < Wp)
-          nd = *reinterpret_cast<const float4*>(dpool + (((size_t)b * Hp + hp) * Wp + wpi) * C + 4 * q);
-      }
-    }
+    const int it = min(item, nitems - 1);  // the last prefetch re-reads the last item: no branch around the loads
+    const int ch = it % chunks;
+    const int row = it / chunks;
+    const int h = row % H;
+    const int b = row / H;
+    const int w = min(ch * (GB16_THREADS / 4) + col, W - 1);
+    const size_t pos = ((size_t)b * H + h) * W + w;
+    ny = *reinterpret_cast<const float4*>(y + pos * C + 4 * q);
+    const int hp = min(h >> sph, Hp - 1), wpi = min(w >> spw, Wp - 1);
+    nd = *reinterpret_cast<const float4*>(dpool + (((size_t)b * Hp + hp) * Wp + wpi) * C + 4 * q);
   };
   fetch(blockIdx.x);
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
@@ -163,71 +155,50 @@ __global__ __launch_bounds__(GS_THREADS) void glu16_bwd_kernel(
     const int row = item / chunks;
     const int h = row % H;
     const int b = row / H;
-    const int w = ch * (GS_THREADS / 4) + col;
+    const int w = ch * (GB16_THREADS / 4) + col;
     const bool ok = w < W;
-    const size_t pos = ((size_t)b * H + h) * W + w;
+    const size_t pos = ((size_t)b * H + h) * W + min(w, W - 1);
+    const float okf = ok ? 1.0f : 0.0f;
+    const float pmask = (ok && (h >> sph) < Hp && (w >> spw) < Wp) ? inv : 0.f;
     const float yv[4] = {cy.x, cy.y, cy.z, cy.w};
     const float dres[4] = {cd.x, cd.y, cd.z, cd.w};
     f4 xs[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xs[0].v[i] = ok ? fmaf(yv[i], sc[i], sh[i]) : 0.f;
-#pragma unroll
-    for (int s = 1; s < 4; ++s) xs[s] = shfl_xor4(xs[0], s);
-    float lin[4] = {bi[0], bi[1], bi[2], bi[3]};
-    if (MODE == 0) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) lin[i] = fmaf(wp[s][i][kk], xs[s].v[kk], lin[i]);
-    }
-    float dl[4], g[4];
+    for (int i = 0; i < 4; ++i) xs[0].v[i] = fmaf(yv[i], sc[i], sh[i]);
+    const f32x4 lin = mm16(a1, xs[0].v[0], xs[0].v[1], xs[0].v[2], xs[0].v[3], f32x4{0.f, 0.f, 0.f, 0.f});
+    float dl[4];
+    f32x4 gt;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float sg = sigmoid_fast(xs[0].v[i]);
-      const float dr = dres[i] * inv * drop_mul((uint64_t)pos * C + 4 * q + i, dkey, dthr, dscale);
+      const float dr = dres[i] * pmask * drop_mul((uint64_t)pos * C + 4 * q + i, dkey, dthr, dscale);
       dl[i] = dr * sg;
-      g[i] = dr * lin[i] * sg * (1.0f - sg);
+      gt[i] = dr * (lin[i] + bi[i]) * sg * (1.0f - sg);
     }
-    // g[k] += sum_c d_lin[c] W[c][k]: own rows c against every column block, reduce-scatter over the group
+    const f32x4 g = mm16(a2, dl[0], dl[1], dl[2], dl[3], gt);  // g = d_lin W + gate term
+    float* gdst = ok ? g_out + pos * C + 4 * q : g16_sink + 4 * (tid & 63);
+    *reinterpret_cast<float4*>(gdst) = make_float4(g[0], g[1], g[2], g[3]);
 #pragma unroll
-    for (int s = 0; s < (MODE == 0 ? 4 : 0); ++s) {
-      f4 ps;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a = fmaf(dl[i], wp[s][i][kk], a);
-        ps.v[kk] = a;
-      }
-      if (s > 0) ps = shfl_xor4(ps, s);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) g[kk] += ps.v[kk];
+    for (int i = 0; i < 4; ++i) {
+      dba[i] += dl[i];
+      sga[i] = fmaf(okf, g[i], sga[i]);
+      sgya[i] = fmaf(okf * g[i], yv[i], sgya[i]);
     }
-    if (ok) {
-      if (MODE == 0) {
-        *reinterpret_cast<float4*>(g_out + pos * C + 4 * q) = make_float4(g[0], g[1], g[2], g[3]);
+    // dW[4q+i][.] += d_lin[i] * xn[.]: the other three quarters of xn come from the lanes 16, 32, 48 apart
+    // (idle columns carry d_lin = 0, so their clamped xn contributes nothing)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          dba[i] += dl[i];
-          sga[i] += g[i];
-          sgya[i] = fmaf(g[i], yv[i], sgya[i]);
-        }
-      } else {
+    for (int s = 1; s < 4; ++s) xs[s] = shfl_xor4(xs[0], 16 * s);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) dwa[s][i][kk] = fmaf(dl[i], xs[s].v[kk], dwa[s][i][kk]);
-      }
-    }
+        for (int kk = 0; kk < 4; ++kk) dwa[s][i][kk] = fmaf(dl[i], xs[s].v[kk], dwa[s][i][kk]);
   }
 
-  // workgroup reduction over the 128 threads that share a quad index q, 16 values per pass
+  // workgroup reduction over the 128 threads that share a quarter index q, 16 values per pass
 #pragma unroll
-  for (int pass = (MODE == 0 ? 4 : 0); pass < (MODE == 0 ? 5 : 4); ++pass) {
+  for (int pass = 0; pass < 5; ++pass) {
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -240,7 +211,8 @@ __global__ __launch_bounds__(GS_THREADS) void glu16_bwd_kernel(
     if (tid < 64) {
       const int rq = tid & 3, j = tid >> 2;
       float s = 0.f;
-      for (int t = rq; t < GS_THREADS; t += 4) s += red[t * 17 + j];
+      for (int wv = 0; wv < GB16_THREADS / 64; ++wv)
+        for (int pp = 0; pp < 16; ++pp) s += red[(wv * 64 + 16 * rq + pp) * 17 + j];
       const size_t gblk = blockIdx.x;
       if (pass < 4) {
         part_dw[(gblk * C + 4 * rq + (j >> 2)) * C + 4 * (rq ^ pass) + (j & 3)] = s;
@@ -280,10 +252,8 @@ extern "C" int bsed_glu16_bwd(const float* y, const float* scale, const float* s
   BSED_CHECK_ARG(C == GS_C, "bsed_glu16_bwd: built for C=16 (got %d)", C);
   BSED_CHECK_ARG(B > 0 && H > 0 && W > 0 && G > 0 && (ph == 1 || ph == 2) && (pw == 1 || pw == 2) && W % pw == 0,
                  "bsed_glu16_bwd: bad shape");
-  BSED_CHECK_ARG((long)B * H * ((W + 127) / 128) + G < (1L << 31), "bsed_glu16_bwd: too many rows");
-  hipLaunchKernelGGL(glu16_bwd_kernel<0>, dim3(G), dim3(GS_THREADS), 0, (hipStream_t)stream, y, scale, shift, wg, bg,
-                     dpool, g_out, part_dw, part_db, part_st, B, H, W, ph, pw, drop_p, rng_stream, seed);
-  hipLaunchKernelGGL(glu16_bwd_kernel<1>, dim3(G), dim3(GS_THREADS), 0, (hipStream_t)stream, y, scale, shift, wg, bg,
+  BSED_CHECK_ARG((long)B * H * ((W + 63) / 64) + G < (1L << 31), "bsed_glu16_bwd: too many rows");
+  hipLaunchKernelGGL(glu16_bwd_kernel, dim3(G), dim3(GB16_THREADS), 0, (hipStream_t)stream, y, scale, shift, wg, bg,
                      dpool, g_out, part_dw, part_db, part_st, B, H, W, ph, pw, drop_p, rng_stream, seed);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
