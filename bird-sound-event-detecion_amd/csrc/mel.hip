@@ -25,7 +25,8 @@
 
 #define NFFT 2048
 #define NC 1024  // complex points
-#define FPB 16   // frames per workgroup
+#define FPB 8    // frames per workgroup (8: with the magnitudes aliased onto the free FFT buffer the workgroup needs
+                 // 39 KB of LDS and four of them fit per CU; the kernel is barrier-latency bound, occupancy is what pays)
 #define MEL_THREADS 256
 
 struct MelPlan {
@@ -97,9 +98,8 @@ __global__ __launch_bounds__(MEL_THREADS) void stft_mel_kernel(
   extern __shared__ __align__(16) unsigned char smem_raw[];
   float2* bufA = reinterpret_cast<float2*>(smem_raw);  // [1024]
   float2* bufB = bufA + NC;                            // [1024]
-  float2* tw = bufB + NC;                              // [1024]
-  float* mag = reinterpret_cast<float*>(tw + NC);      // [1025] (+3 pad)
-  float* span = mag + 1028;                            // [span_len]
+  const float2* tw = w1024;                            // twiddles straight from global memory (8 KB, L1-resident)
+  float* span = reinterpret_cast<float*>(bufB + NC);   // [span_len]
 
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -107,7 +107,6 @@ __global__ __launch_bounds__(MEL_THREADS) void stft_mel_kernel(
   const float* w = wav + (size_t)b * n_samples;
 
   // stage twiddles + the sample span (reflect padding of librosa.stft(center=True))
-  for (int i = tid; i < NC; i += MEL_THREADS) tw[i] = w1024[i];
   const long g0 = (long)t0 * hop - NFFT / 2;
   for (int i = tid; i < span_len; i += MEL_THREADS) {
     long g = g0 + i;
@@ -157,7 +156,8 @@ __global__ __launch_bounds__(MEL_THREADS) void stft_mel_kernel(
       __syncthreads();
       float2* tmp = src; src = dst; dst = tmp;
     }
-    // real-FFT unpack: X[k] = Fe + W2048^k * Fo ; magnitude into LDS
+    // real-FFT unpack: X[k] = Fe + W2048^k * Fo ; magnitudes into the buffer the last stage left free
+    float* mag = reinterpret_cast<float*>(dst);  // 1025 floats of its 2048
     for (int k = tid; k <= NC; k += MEL_THREADS) {
       const float2 zk = src[k & (NC - 1)];
       const float2 zr = src[(NC - k) & (NC - 1)];
@@ -329,7 +329,7 @@ extern "C" int bsed_mel_linear(const void* plan, const float* wav, int B, int n_
   hipStream_t s = (hipStream_t)stream;
   const int T = 1 + n_samples / p->cfg.hop;
   const int span_len = NFFT + (FPB - 1) * p->cfg.hop;
-  const size_t smem = 3 * NC * sizeof(float2) + 1028 * sizeof(float) + (size_t)span_len * sizeof(float);
+  const size_t smem = 2 * NC * sizeof(float2) + (size_t)span_len * sizeof(float);
   BSED_CHECK_ARG(smem <= 160 * 1024, "bsed_mel_linear: hop %d needs %zu B of LDS", p->cfg.hop, smem);
   BSED_HIP(hipMemsetAsync(clip_max, 0, (size_t)B * sizeof(float), s));
   BSED_HIP(hipMemsetAsync(bin_sumsq, 0, (size_t)B * p->cfg.n_mels * sizeof(float), s));
