@@ -390,21 +390,25 @@ __global__ void glu3_pack_frags_kernel(const float* __restrict__ w, bf16x8* __re
   WB[((j * KS + ks) * 2 + 1) * 64 + lane] = lo;
 }
 
-__global__ __launch_bounds__(G3_THREADS, 1) void glu_bwd3n_kernel(const Glu3Params P, const bf16x8* __restrict__ table,
-                                                                  float* __restrict__ dlin) {
+// Eight waves share the 128 KB of weights: waves 0-3 and 4-7 work on two different 128-position tiles (no barrier
+// inside the tile loop), which puts two waves on every SIMD instead of one.
+#define G3N_THREADS 512
+__global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params P, const bf16x8* __restrict__ table,
+                                                                float* __restrict__ dlin) {
   constexpr int C = 128, NT = 4, KS = 8;
-  constexpr int DQ = 2 * 32 + 8;  // ushorts per row of the quarter tile: 32 hi | 32 lo | 8 pad (144 B = 9 x 16 B)
+  constexpr int DQ = 2 * 16 + 8;  // ushorts per row of the 16-channel chunk tile: 16 hi | 16 lo | 8 pad (80 B = 5 x 16 B)
   extern __shared__ __align__(16) unsigned char smem_raw[];
   bf16x8* WF = reinterpret_cast<bf16x8*>(smem_raw);
   bf16x8* WB = WF + NT * KS * 2 * 64;
   float* s_sc = reinterpret_cast<float*>(WB + NT * KS * 2 * 64);
   float* s_sh = s_sc + C;
   unsigned short* Dall = reinterpret_cast<unsigned short*>(s_sh + C);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  unsigned short* D = Dall + wave * 32 * DQ;  // wave-private
+  const int tid = threadIdx.x, wave8 = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = wave8 & 3, half = wave8 >> 2;  // wave = 32-row block of the tile, half = which of the two tiles
+  unsigned short* D = Dall + wave8 * 32 * DQ;  // wave-private
 
-  for (int i = tid; i < 2 * NT * KS * 2 * 64; i += G3_THREADS) WF[i] = table[i];
-  for (int i = tid; i < C; i += G3_THREADS) { s_sc[i] = P.scale[i]; s_sh[i] = P.shift[i]; }
+  for (int i = tid; i < 2 * NT * KS * 2 * 64; i += G3N_THREADS) WF[i] = table[i];
+  for (int i = tid; i < C; i += G3N_THREADS) { s_sc[i] = P.scale[i]; s_sh[i] = P.shift[i]; }
   __syncthreads();
 
   const int sph = P.ph >> 1, spw = P.pw >> 1;
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(G3_THREADS, 1) void glu_bwd3n_kernel(const Glu3Para
     sdb[j] = 0.f; sgs[j] = 0.f; sgy[j] = 0.f;
   }
 
-  for (int tile0 = blockIdx.x; tile0 < P.ntiles; tile0 += gridDim.x) {
+  for (int tile0 = 2 * blockIdx.x + half; tile0 < P.ntiles; tile0 += 2 * gridDim.x) {
     int tile = tile0;
     const int tw_i = tile % P.tilesW; tile /= P.tilesW;
     const int th_i = tile % P.tilesH;
@@ -495,33 +499,32 @@ __global__ __launch_bounds__(G3_THREADS, 1) void glu_bwd3n_kernel(const Glu3Para
         }
     }
 
-    // ---- GEMM2 in four K quarters: g = d_lin W + gate term (already in acc)
+    // ---- GEMM2 in eight 16-channel K chunks: g = d_lin W + gate term (already in acc)
     acc_handoff_fence<NT>(acc);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 8; ++q) {
+      // chunk q = channels 16q..16q+15 = C-layout tile j = q/2, lanes li in [16*(q&1), 16*(q&1) + 16)
+      if ((li >> 4) == (q & 1)) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = 2 * i;  // packed pair (r, r+1): rows crow(r), crow(r)+1
-        const int row = 8 * (r >> 2) + lhv + (r & 3);
-        D[row * DQ + li] = (unsigned short)(dph[q][i] & 0xFFFFu);
-        D[(row + 1) * DQ + li] = (unsigned short)(dph[q][i] >> 16);
-        D[row * DQ + 32 + li] = (unsigned short)(dpl[q][i] & 0xFFFFu);
-        D[(row + 1) * DQ + 32 + li] = (unsigned short)(dpl[q][i] >> 16);
+        for (int i = 0; i < 8; ++i) {
+          const int r = 2 * i;  // packed pair (r, r+1): rows crow(r), crow(r)+1
+          const int row = 8 * (r >> 2) + lhv + (r & 3);
+          D[row * DQ + (li & 15)] = (unsigned short)(dph[q >> 1][i] & 0xFFFFu);
+          D[(row + 1) * DQ + (li & 15)] = (unsigned short)(dph[q >> 1][i] >> 16);
+          D[row * DQ + 16 + (li & 15)] = (unsigned short)(dpl[q >> 1][i] & 0xFFFFu);
+          D[(row + 1) * DQ + 16 + (li & 15)] = (unsigned short)(dpl[q >> 1][i] >> 16);
+        }
       }
       wave_lds_fence();
+      const bf16x8 d_hi = *reinterpret_cast<const bf16x8*>(D + li * DQ + 8 * lh);
+      const bf16x8 d_lo = *reinterpret_cast<const bf16x8*>(D + li * DQ + 16 + 8 * lh);
 #pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        const int ks = 2 * q + k2;
-        const bf16x8 d_hi = *reinterpret_cast<const bf16x8*>(D + li * DQ + 16 * k2 + 8 * lh);
-        const bf16x8 d_lo = *reinterpret_cast<const bf16x8*>(D + li * DQ + 32 + 16 * k2 + 8 * lh);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const bf16x8 b_hi = WB[((j * KS + ks) * 2 + 0) * 64 + lane];
-          const bf16x8 b_lo = WB[((j * KS + ks) * 2 + 1) * 64 + lane];
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_lo, b_hi, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_hi, b_lo, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_hi, b_hi, acc[j], 0, 0, 0);
-        }
+      for (int j = 0; j < NT; ++j) {
+        const bf16x8 b_hi = WB[((j * KS + q) * 2 + 0) * 64 + lane];
+        const bf16x8 b_lo = WB[((j * KS + q) * 2 + 1) * 64 + lane];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_lo, b_hi, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_hi, b_lo, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_hi, b_hi, acc[j], 0, 0, 0);
       }
       wave_lds_fence();
     }
@@ -555,23 +558,24 @@ __global__ __launch_bounds__(G3_THREADS, 1) void glu_bwd3n_kernel(const Glu3Para
   }
 
   __syncthreads();
-  float* red = reinterpret_cast<float*>(Dall);  // [4 waves][3][C] = 6 KB of the 18 KB tile area
+  float* red = reinterpret_cast<float*>(Dall);  // [8 waves][3][C] = 12 KB of the 20 KB tile area
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const float a = sdb[j] + __shfl_xor(sdb[j], 32, 64);
     const float b = sgs[j] + __shfl_xor(sgs[j], 32, 64);
     const float c = sgy[j] + __shfl_xor(sgy[j], 32, 64);
     if (lh == 0) {
-      red[(wave * 3 + 0) * C + 32 * j + li] = a;
-      red[(wave * 3 + 1) * C + 32 * j + li] = b;
-      red[(wave * 3 + 2) * C + 32 * j + li] = c;
+      red[(wave8 * 3 + 0) * C + 32 * j + li] = a;
+      red[(wave8 * 3 + 1) * C + 32 * j + li] = b;
+      red[(wave8 * 3 + 2) * C + 32 * j + li] = c;
     }
   }
   __syncthreads();
-  for (int e = tid; e < 3 * C; e += G3_THREADS) {
+  for (int e = tid; e < 3 * C; e += G3N_THREADS) {
     const int which = e / C, n = e % C;
-    const float s = red[(0 * 3 + which) * C + n] + red[(1 * 3 + which) * C + n] + red[(2 * 3 + which) * C + n] +
-                    red[(3 * 3 + which) * C + n];
+    float s = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 8; ++wv) s += red[(wv * 3 + which) * C + n];
     if (which == 0) {
       P.part_db[((size_t)blockIdx.x * 2 + 0) * C + n] = s;
       P.part_db[((size_t)blockIdx.x * 2 + 1) * C + n] = 0.f;
@@ -821,19 +825,20 @@ extern "C" int bsed_glu_bwd3n(const float* y, const float* scale, const float* s
   Glu3Params P;
   int rc = fill_params(P, NB, H, W, C, TH, TW, ph, pw, "bsed_glu_bwd3n");
   if (rc) return rc;
-  BSED_CHECK_ARG(G > 0 && G <= P.ntiles, "bsed_glu_bwd3n: G must be in 1..%d tiles", P.ntiles);
+  BSED_CHECK_ARG(G > 0 && 2 * (G - 1) < P.ntiles, "bsed_glu_bwd3n: G workgroups take two tiles at a time: 1..%d",
+                 (P.ntiles + 1) / 2);
   P.y = y; P.scale = scale; P.shift = shift; P.w = w; P.bias = bias; P.dpool = dpool;
   P.g = g; P.part_dw = nullptr; P.part_db = part_db; P.part_st = part_st; P.pooled = nullptr;
   P.drop_p = drop_p; P.rng_stream = rng_stream; P.seed = seed;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(glu3_pack_frags_kernel, dim3(4 * 8 * 64 / 256), dim3(256), 0, s, w, (bf16x8*)frag_table);
-  const size_t smem = bsed_glu_bwd3n_table_bytes() + 2 * 128 * sizeof(float) + (size_t)4 * 32 * (2 * 32 + 8) * 2;
+  const size_t smem = bsed_glu_bwd3n_table_bytes() + 2 * 128 * sizeof(float) + (size_t)8 * 32 * (2 * 16 + 8) * 2;
   static bool done = false;
   if (!done) {
     BSED_HIP(hipFuncSetAttribute((const void*)glu_bwd3n_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
-  hipLaunchKernelGGL(glu_bwd3n_kernel, dim3(G), dim3(G3_THREADS), smem, s, P, (const bf16x8*)frag_table, dlin);
+  hipLaunchKernelGGL(glu_bwd3n_kernel, dim3(G), dim3(G3N_THREADS), smem, s, P, (const bf16x8*)frag_table, dlin);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }

@@ -418,7 +418,7 @@ def glu_bwd3n(y, scale, shift, w, bias, dpool, B, H, W, C, pool, drop_p, rng_str
     dev = y.device
     TH, TW = tile_for(W)
     ntiles = B * ((H + TH - 1) // TH) * (W // TW)
-    G = int(min(ntiles, 256))
+    G = int(min((ntiles + 1) // 2, 256))  # 8-wave workgroups take two tiles at a time
     tb = _frag_tables.get(str(dev))
     if tb is None:
         fn = L.lib().bsed_glu_bwd3n_table_bytes
