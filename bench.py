@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
     ap.add_argument("--sr", type=int, default=22050, help="22050 = BASELINE measurement config, 32000 = reference config")
     ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--mode", choices=["crnn", "mt", "ada"], default="crnn",
+                    help="crnn = BASELINE configs[2] (the headline metric); mt = configs[3] (student + EMA teacher + "
+                         "consistency, half the batch synthetic, half real); ada = configs[4] (domain-adversarial head)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -142,7 +145,19 @@ def main():
     weights_init(crnn); weights_init(pred)
     mcfg = MelConfig(sr=args.sr)
     fe = MelFrontEnd(mcfg)
-    tr = SEDTrainer(crnn, pred, optimizer=FlatAdam([crnn, pred], lr=1e-3), frontend=fe, seed=2023)
+    extra = {}
+    if args.mode == "mt":
+        # reference src/main_scmt.py: the teacher is a second CRNN/Predictor pair that only ever receives the EMA
+        ema_c, ema_p = CRNN(**kw), Predictor(nclass=20, attention=True, n_RNN_cell=128)
+        ema_c.load_state_dict(crnn.state_dict()); ema_p.load_state_dict(pred.state_dict())
+        extra = dict(ema_crnn=ema_c, ema_predictor=ema_p)
+    elif args.mode == "ada":
+        from bsed_amd.disc import Clip_Discriminator, ConditionalDomainAdversarialLoss
+        from bsed_amd.engine import FlatSGD
+        disc = Clip_Discriminator()
+        extra = dict(domain_loss=ConditionalDomainAdversarialLoss(disc),
+                     optimizer_d=FlatSGD([disc], lr=1e-4, momentum=0.9, weight_decay=0.0))
+    tr = SEDTrainer(crnn, pred, optimizer=FlatAdam([crnn, pred], lr=1e-3), frontend=fe, seed=2023, **extra)
     tr.broadcast_parameters()
 
     B, n = args.batch, int(args.seconds * args.sr)
@@ -151,8 +166,17 @@ def main():
     Tp = T // 4
     y = strong_labels(ev, Tp, args.sr, mcfg.hop_size, 4, dev)
 
-    def step():
-        return tr.train_step(wav, y, from_wave=True)
+    if args.mode == "crnn":
+        def step():
+            return tr.train_step(wav, y, from_wave=True)
+    else:
+        # half the clips play the synthetic (strongly labelled) batch, half the real batch (weak labels for mt)
+        h = B // 2
+        wav_s, y_s, wav_r = wav[:h].contiguous(), y[:h].contiguous(), wav[h:].contiguous()
+        yw_r = y[h:].max(1)[0].contiguous() if args.mode == "mt" else None
+
+        def step():
+            return tr.train_step(wav_s, y_s, wav_r, yw_r, from_wave=True)
 
     def log(msg):
         if rank == 0:
@@ -251,7 +275,7 @@ def main():
         # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # passes, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for the profiled workload
         try:
-            if B == 256 and args.sr == 22050 and args.seconds == 10.0:
+            if args.mode == "crnn" and B == 256 and args.sr == 22050 and args.seconds == 10.0:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(name)
                 if pmc:
                     roofline["traffic"] = round(pmc["hbm_bytes_per_launch"])
@@ -266,14 +290,21 @@ def main():
             ncpu = os.cpu_count() or 1
         cpu = cpu_baseline(args.sr, args.seconds, max(1, min(ncpu, 16)))
         log("cpu baseline done")
+    workload = {
+        "crnn": "waveform->STFT/mel/dB->CRNN(7 conv/BN/GLU/pool + 2xBiGRU128)->Predictor->BCE strong+weak"
+                "->backward->Adam; BASELINE configs[2] (main_baseline.py train step on SYN)",
+        "mt": "mean teacher: student on B/2 synthetic + B/2 real clips, EMA teacher forward on the noisy real half, "
+              "consistency MSE, backward, Adam, EMA update; BASELINE configs[3] (main_scmt.py)",
+        "ada": "domain-adversarial: student on B/2 synthetic + B/2 real clips, Clip_Discriminator + gradient reverse "
+               "on both encodings, backward, Adam + SGD(discriminator); BASELINE configs[4] (main_scmt_ada_weak.py)",
+    }[args.mode]
     line = {
         "metric": "10 s clips/sec through mel+CRNN train step", "value": round(value, 2), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "contraction_mode": os.environ.get("BSED_CONV_MODE", "bf16x3"),
-        "config": {"workload": "waveform->STFT/mel/dB->CRNN(7 conv/BN/GLU/pool + 2xBiGRU128)->Predictor->BCE strong+weak"
-                               "->backward->Adam; BASELINE configs[2] (main_baseline.py train step on SYN)",
+        "config": {"workload": workload, "mode": args.mode,
                    "clip_seconds": args.seconds, "sr": args.sr, "frames": T, "out_frames": Tp,
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "dropout": 0.5},
         "roofline": roofline, "cpu_baseline": cpu, "final_loss": round(loss, 5),

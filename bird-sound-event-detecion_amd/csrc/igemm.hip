@@ -21,7 +21,7 @@
 
 #define IG_THREADS 256
 #define IG_TILE_M 128
-#define W3_RD 136  // ushorts per transposed dy row: 128 positions + 8 pad (272 B keeps b128 fragment reads conflict-free)
+#define W3_DY_BYTES (2 * IG_TILE_M * 32 * 2)  // bf16x3 weight gradient: LDS bytes of one 32-channel dy tile (hi + lo planes)
 
 enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_GLU_POOL = 2, EPI_GLU_BWD = 3, EPI_ADD_STATS2 = 4 };
 
@@ -426,51 +426,74 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(const WgradParams P) {
 // ---------------------------------------------------------------------------------------------
 // weight gradient with split-fp32 operands on the bf16 matrix cores (bf16x3, see igemm3.hip).  K of the GEMM is the
 // position index, so a lane's fragment is 8 POSITIONS of one channel:
-//   * dy is staged TRANSPOSED ([n][128 positions], bf16 hi / lo planes) -> one 16-byte read per fragment;
-//   * the activation patch stays position-major, each element one 32-bit word (hi | lo << 16); the tap-shifted
-//     fragment is gathered with 8 ds_read_b32 (lanes = consecutive channels: conflict-free) and unpacked with
-//     v_perm -- 8 LDS reads replace 8 x 64-cycle fp32 MFMAs by 3 x 32-cycle bf16 MFMAs.
+//   * dy is staged TRANSPOSED ([n][128 positions], bf16 hi / lo planes) -> one 16-byte read per fragment, and a wave
+//     whose work items all share the dy tile reads it once per K step;
+//   * the activation patch stays position-major (as it arrives from HBM) in two bf16 planes (hi, lo); the tap-shifted
+//     fragment comes out of gfx950's transposing LDS read: one ds_read_b64_tr_b16 hands every lane 4 consecutive
+//     positions of its channel, whatever the row pitch, so a tap shift is an address offset.  4 such reads (2 LDS cycles
+//     each, no VALU) replace the 8 ds_read_b32 + 8 v_perm of a word-packed patch, which had made this kernel
+//     LDS-bandwidth bound (4 SIMDs x 24 LDS cycles per 96 MFMA cycles).
+// Rows of 32 channels are 64-byte chunks; a fragment read touches 4 consecutive patch columns of one chunk, so the
+// chunk index is XOR-swizzled with the patch COLUMN (invariant under row steps): 4 columns x 64 B tile the 64 banks.
 // ---------------------------------------------------------------------------------------------
 typedef short w3_bf16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t w3_u32x4 __attribute__((ext_vector_type(4)));
+typedef short w3_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned short w3_lds_u16;
+typedef __attribute__((address_space(3))) w3_bf16x4 w3_lds_v4;
+typedef uint32_t w3_u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) w3_u32x2 w3_lds_u2;
 
-// one element -> word (bf16 hi | bf16 lo << 16); two elements share the packed hardware conversions
-__device__ __forceinline__ void w3_split2(float a, float b, uint32_t& wa, uint32_t& wb) {
-  uint32_t hi, lo;
-  bsed_split2(a, b, hi, lo);
-  wa = __builtin_amdgcn_perm(lo, hi, 0x05040100u);  // (lo.a << 16) | hi.a
-  wb = __builtin_amdgcn_perm(lo, hi, 0x07060302u);  // (lo.b << 16) | hi.b
-}
-__device__ __forceinline__ uint4 w3_split4(float a, float b, float c, float d) {
-  uint4 r;
-  w3_split2(a, b, r.x, r.y);
-  w3_split2(c, d, r.z, r.w);
-  return r;
-}
-__device__ __forceinline__ uint32_t w3_split(float x) {
-  uint32_t wa, wb;
-  w3_split2(x, x, wa, wb);
-  return wa;
+// physical 32-channel chunk of logical chunk `ch` in the row of position / patch column pc (nch = chunks per row: 1, 2
+// or 4): 4 consecutive pc x 64 B then tile the 64 banks
+__device__ __forceinline__ int w3_chunk(int ch, int pc, int nch) {
+  return ch ^ ((nch == 2 ? (pc >> 1) : pc) & (nch - 1));
 }
 
-template <int MAXS, int NW>
-__global__ __launch_bounds__(NW * 64) void wgrad3_kernel(const WgradParams P) {
+// 8 consecutive positions of this lane's channel: two transposing reads of 4 rows each.  a0 / a1 are LDS BYTE
+// addresses (plane base included, so that no base add is left in the K loop)
+__device__ __forceinline__ w3_bf16x8 w3_frag(uint32_t a0, uint32_t a1) {
+  const w3_bf16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((w3_lds_v4*)(uintptr_t)a0);
+  const w3_bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((w3_lds_v4*)(uintptr_t)a1);
+  return __builtin_shufflevector(u, v, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// 4 channels of one position -> the two planes
+__device__ __forceinline__ void w3_store4(w3_lds_u16* hi_plane, w3_lds_u16* lo_plane, int o, const float4& v) {
+  w3_u32x2 hi, lo;
+  uint32_t h0, l0, h1, l1;
+  bsed_split2(v.x, v.y, h0, l0);
+  bsed_split2(v.z, v.w, h1, l1);
+  hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
+  *(w3_lds_u2*)(hi_plane + o) = hi;
+  *(w3_lds_u2*)(lo_plane + o) = lo;
+}
+
+template <int MAXS, int NW, bool BS>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) void wgrad3_kernel(const WgradParams P) {
   constexpr int NTHR = NW * 64;
   const BsedWgradDesc& p = P.d;
   extern __shared__ __align__(16) uint32_t smw[];
   const int CC = P.CC;
   const int cz0 = blockIdx.z * CC;
-  uint32_t* Xw = smw;                                                       // [PP][CC] words (hi | lo << 16)
-  unsigned short* DYh = reinterpret_cast<unsigned short*>(smw + P.dy_off);  // [DYW][W3_RD]
   const int DYW = 32 * P.ntw;
-  unsigned short* DYl = DYh + DYW * W3_RD;
+  w3_lds_u16* Xh = (w3_lds_u16*)smw;               // [PP][CC] bf16, chunk-swizzled
+  w3_lds_u16* Xl = Xh + P.PP * CC;
+  w3_lds_u16* DYh = Xh + 2 * P.dy_off;             // [128][DYW] bf16, chunk-swizzled
+  w3_lds_u16* DYl = DYh + IG_TILE_M * DYW;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.y * DYW;
   const int PW = P.PW;
   const int ntap_items = P.pack2 ? (p.ntaps + 1) / 2 : p.ntaps;
   const int nitems = ntap_items * P.nct * P.ntw;
+  // transposing read: lane 16g + 4q + c4 supplies the address of row (position) q, columns 4*c4 .. 4*c4+3 of its
+  // 16-lane group's 4 x 16 block and receives column (lane & 15), rows 0..3 -- the operand layout of v_mfma_32x32x16
+  // (row / column = lane & 31 = 16 * (g & 1) + block column, k = 8 * (lane >> 5) + 4 * read + block row)
+  const int gq = (lane >> 2) & 3, gc = 4 * (lane & 3), gh = (lane >> 4) & 1;
 
-  int xoff[MAXS], boff[MAXS];
+  constexpr int NB_ = BS ? 1 : MAXS;
+  const uint32_t xh0 = (uint32_t)(uintptr_t)Xh, dh0 = (uint32_t)(uintptr_t)DYh;
+  const uint32_t xlo = 2 * P.PP * CC, dlo = 2 * IG_TILE_M * DYW;  // byte distance hi plane -> lo plane
+  uint32_t xa[MAXS][2], xb[NB_][2];
   bool valid[MAXS];
   f32x16 acc[MAXS];
 #pragma unroll
@@ -479,23 +502,28 @@ __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(const WgradParams P) {
     valid[s] = it < nitems;
     const int cit = valid[s] ? it % P.nct : 0, rr = valid[s] ? it / P.nct : 0;
     const int nt = rr % P.ntw, tap = rr / P.ntw;
+    int tp = tap, col = 16 * gh + gc;
     if (P.pack2) {
-      const int ta = 2 * tap, tb = 2 * tap + 1;
-      if (li < 16 || tb >= p.ntaps) xoff[s] = (p.dh[ta] * PW + p.dw[ta]) * CC + li;
-      else xoff[s] = (p.dh[tb] * PW + p.dw[tb]) * CC + (li - 16);
-    } else {
-      xoff[s] = (p.dh[tap] * PW + p.dw[tap]) * CC + cit * 32 + li;
+      // rows 0..15 of the tile: tap 2*tap, rows 16..31: tap 2*tap+1 (channels 16..31 of the staged patch are zero,
+      // which is what the upper rows read when the second tap does not exist)
+      const int tb = 2 * tap + 1;
+      tp = 2 * tap;
+      if (gh && tb < p.ntaps) { tp = tb; col = gc; }
     }
-    boff[s] = (nt * 32 + li) * W3_RD + 8 * lh;
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int mk = 8 * lh + 4 * rd + gq;
+      const int pr = (mk >> P.lgTW) + p.hh + p.dh[tp], pc = (mk & (p.TW - 1)) + p.hw + p.dw[tp];
+      xa[s][rd] = xh0 + 2 * ((pr * PW + pc) * CC + (w3_chunk(cit, pc, P.nct) << 5) + col);
+      if (!BS || s == 0) xb[BS ? 0 : s][rd] = dh0 + 2 * (mk * DYW + (w3_chunk(nt, mk, P.ntw) << 5) + 16 * gh + gc);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
   }
-  int pidx0[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int mk = 8 * lh + j;
-    pidx0[j] = (((mk >> P.lgTW) + p.hh) * PW + (mk & (p.TW - 1)) + p.hw) * CC;
-  }
+  // BS: all of a wave's items sit on one dy tile (the wave stride NW is a multiple of channel tiles x dy tiles), so
+  // its fragment is read once per K step
+  const uint32_t kstep = 2 * (16 >> P.lgTW) * PW * CC;  // bytes; 16 positions = (16 / TW) tile rows (TW <= 16)
+  const uint32_t bstep = 2 * 16 * DYW;
 
   for (int tile0 = blockIdx.x; tile0 < P.ntiles; tile0 += gridDim.x) {
     int tile = tile0;
@@ -506,85 +534,104 @@ __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(const WgradParams P) {
     const float* inb = p.in + (size_t)nb * p.H * p.W * p.in_pitch;
     const float* dyb = p.dy + (size_t)nb * p.H * p.W * p.dy_pitch;
     __syncthreads();
-    // activation patch -> packed split words
+    // Both tiles arrive as coalesced float4 rows and stay position-major.  The loads of a round are all issued before
+    // any is consumed: the staging phase is a chain of global-load latencies, so fewer, wider rounds is what counts
+    // (a 180-position x 64-channel patch is 12 float4 per thread: two rounds of 6 instead of three of 4).
+    constexpr int UX = 6, UD = 8;
     const int c4n = 1 << P.lgc4;
     const int x_total = P.PP * c4n;
-    for (int e0 = tid; e0 < x_total; e0 += 4 * NTHR) {
-      float4 v[4];
-      bool okv[4];
+    for (int e0 = tid; e0 < x_total; e0 += UX * NTHR) {
+      float4 v[UX];
+      bool okv[UX];
+      int ov[UX];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UX; ++u) {
         const int e = e0 + u * NTHR;
         const int c4 = e & (c4n - 1), pos = e >> P.lgc4;
         const int pr = (pos * P.pw_magic) >> 20, pc = pos - pr * PW;
-        const int gh = th0 - p.hh + pr, gw = tw0 - p.hw + pc;
+        const int gh_ = th0 - p.hh + pr, gw = tw0 - p.hw + pc;
         const int cg = cz0 + 4 * c4;
+        ov[u] = pos * CC + (w3_chunk(c4 >> 3, pc, P.nct) << 5) + 4 * (c4 & 7);
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        okv[u] = e < x_total && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W && cg < p.CIN;
-        if (okv[u]) v[u] = *reinterpret_cast<const float4*>(inb + ((size_t)gh * p.W + gw) * p.in_pitch + cg);
+        okv[u] = e < x_total && gh_ >= 0 && gh_ < p.H && gw >= 0 && gw < p.W && cg < p.CIN;
+        if (okv[u]) v[u] = *reinterpret_cast<const float4*>(inb + ((size_t)gh_ * p.W + gw) * p.in_pitch + cg);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UX; ++u) {
         const int e = e0 + u * NTHR;
         if (e < x_total) {
-          const int c4 = e & (c4n - 1), pos = e >> P.lgc4;
           if (p.a_scale && okv[u]) {
-            const int cg = cz0 + 4 * c4;
+            const int cg = cz0 + 4 * (e & (c4n - 1));
             const float4 sc = *reinterpret_cast<const float4*>(p.a_scale + cg);
             const float4 sh = *reinterpret_cast<const float4*>(p.a_shift + cg);
             v[u].x = fmaf(v[u].x, sc.x, sh.x); v[u].y = fmaf(v[u].y, sc.y, sh.y);
             v[u].z = fmaf(v[u].z, sc.z, sh.z); v[u].w = fmaf(v[u].w, sc.w, sh.w);
           }
-          *reinterpret_cast<uint4*>(Xw + pos * CC + 4 * c4) =
-              w3_split4(v[u].x, v[u].y, v[u].z, v[u].w);
+          w3_store4(Xh, Xl, ov[u], v[u]);
         }
       }
     }
-    // dy tile, transposed: thread = (channel n, group of 8 positions)
-    for (int e = tid; e < DYW * 16; e += NTHR) {
-      const int n = e % DYW, g = e / DYW;
-      float f[8];
+    const int n4n = 8 * P.ntw, lgn4 = P.ntw == 4 ? 5 : (P.ntw == 2 ? 4 : 3);
+    const int d_total = IG_TILE_M * n4n;
+    for (int e0 = tid; e0 < d_total; e0 += UD * NTHR) {
+      float4 v[UD];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int mm = 8 * g + j;
-        const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
-        f[j] = (gh < p.H && gw < p.W && n0 + n < p.N) ? dyb[((size_t)gh * p.W + gw) * p.dy_pitch + n0 + n] : 0.f;
+      for (int u = 0; u < UD; ++u) {
+        const int e = e0 + u * NTHR;
+        const int n4 = e & (n4n - 1), mm = e >> lgn4;
+        const int gh_ = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < d_total && gh_ < p.H && gw < p.W && n0 + 4 * n4 < p.N)
+          v[u] = *reinterpret_cast<const float4*>(dyb + ((size_t)gh_ * p.W + gw) * p.dy_pitch + n0 + 4 * n4);
       }
-      uint32_t w[8];
 #pragma unroll
-      for (int j = 0; j < 8; j += 2) w3_split2(f[j], f[j + 1], w[j], w[j + 1]);
-      uint4 hi, lo;
-      hi.x = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u); lo.x = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
-      hi.y = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u); lo.y = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
-      hi.z = __builtin_amdgcn_perm(w[5], w[4], 0x05040100u); lo.z = __builtin_amdgcn_perm(w[5], w[4], 0x07060302u);
-      hi.w = __builtin_amdgcn_perm(w[7], w[6], 0x05040100u); lo.w = __builtin_amdgcn_perm(w[7], w[6], 0x07060302u);
-      *reinterpret_cast<uint4*>(DYh + n * W3_RD + 8 * g) = hi;
-      *reinterpret_cast<uint4*>(DYl + n * W3_RD + 8 * g) = lo;
+      for (int u = 0; u < UD; ++u) {
+        const int e = e0 + u * NTHR;
+        const int n4 = e & (n4n - 1), mm = e >> lgn4;
+        if (e < d_total) w3_store4(DYh, DYl, mm * DYW + (w3_chunk(n4 >> 3, mm, P.ntw) << 5) + 4 * (n4 & 7), v[u]);
+      }
     }
     __syncthreads();
-    for (int kp = 0; kp < IG_TILE_M; kp += 16) {
-      // kp is a multiple of 16 >= TW, so position kp + r (r < 16) sits (kp >> lgTW) tile rows below position r:
-      // the patch index is the tile-invariant pidx0[j] plus a row step (was ~48 VALU instructions per K step)
-      int pidx[8];
-      const int rowoff = (kp >> P.lgTW) * PW * CC;
+    // slots go through the matrix cores in small groups: the fragments of group g+1 are requested before the MFMAs of
+    // group g issue (sched_barrier pins that order), so one LDS latency is exposed per K step, not one per group,
+    // and at most two groups of fragments are live (the 9-slot form has 144 accumulator registers)
+    constexpr int SG = MAXS > 5 ? 2 : 3, NG = (MAXS + SG - 1) / SG;
+    constexpr int SB = BS ? 1 : SG;
+    uint32_t ko = 0, kb = 0;
+#pragma unroll 1
+    for (int kp = 0; kp < IG_TILE_M; kp += 16, ko += kstep, kb += bstep) {
+      w3_bf16x8 ah[2][SG], al[2][SG], bh[2][SB], bl[2][SB];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pidx[j] = pidx0[j] + rowoff;
+      for (int g = 0; g <= NG; ++g) {
+        if (g < NG) {
 #pragma unroll
-      for (int s = 0; s < MAXS; ++s) {
-        uint32_t w[8];
+          for (int j = 0; j < SG; ++j) {
+            const int sl = g * SG + j;
+            if (sl < MAXS) {
+              ah[g & 1][j] = w3_frag(xa[sl][0] + ko, xa[sl][1] + ko);
+              al[g & 1][j] = w3_frag(xa[sl][0] + ko + xlo, xa[sl][1] + ko + xlo);
+              if (!BS || sl == 0) {
+                bh[g & 1][BS ? 0 : j] = w3_frag(xb[BS ? 0 : sl][0] + kb, xb[BS ? 0 : sl][1] + kb);
+                bl[g & 1][BS ? 0 : j] = w3_frag(xb[BS ? 0 : sl][0] + kb + dlo, xb[BS ? 0 : sl][1] + kb + dlo);
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (g > 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = Xw[pidx[j] + xoff[s]];
-        w3_u32x4 ah, al;
-        ah[0] = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u); al[0] = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
-        ah[1] = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u); al[1] = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
-        ah[2] = __builtin_amdgcn_perm(w[5], w[4], 0x05040100u); al[2] = __builtin_amdgcn_perm(w[5], w[4], 0x07060302u);
-        ah[3] = __builtin_amdgcn_perm(w[7], w[6], 0x05040100u); al[3] = __builtin_amdgcn_perm(w[7], w[6], 0x07060302u);
-        const w3_bf16x8 a_hi = __builtin_bit_cast(w3_bf16x8, ah), a_lo = __builtin_bit_cast(w3_bf16x8, al);
-        const w3_bf16x8 b_hi = *reinterpret_cast<const w3_bf16x8*>(DYh + boff[s] + kp);
-        const w3_bf16x8 b_lo = *reinterpret_cast<const w3_bf16x8*>(DYl + boff[s] + kp);
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[s], 0, 0, 0);
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[s], 0, 0, 0);
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[s], 0, 0, 0);
+          for (int j = 0; j < SG; ++j) {
+            const int sl = (g - 1) * SG + j;
+            if (sl < MAXS) {
+              const w3_bf16x8 b_hi = BS ? bh[0][0] : bh[(g - 1) & 1][BS ? 0 : j];
+              const w3_bf16x8 b_lo = BS ? bl[0][0] : bl[(g - 1) & 1][BS ? 0 : j];
+              acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[(g - 1) & 1][j], b_hi, acc[sl], 0, 0, 0);
+              acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[(g - 1) & 1][j], b_lo, acc[sl], 0, 0, 0);
+              acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[(g - 1) & 1][j], b_hi, acc[sl], 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   }
@@ -610,7 +657,6 @@ __global__ __launch_bounds__(NW * 64) void wgrad3_kernel(const WgradParams P) {
   }
 }
 
-// dst[tap*s_tap + k*s_k + n*s_n] (+)= sum_g part[g][tap][k][n]
 __global__ void reduce_partials_kernel(const float* __restrict__ part, int G, int ntaps, int KP, int NP, int K,
                                        int N, float* __restrict__ dst, long s_tap, long s_k, long s_n,
                                        int accumulate) {
@@ -824,7 +870,7 @@ static int wgrad_prepare(const BsedWgradDesc* desc, WgradParams& P, size_t& smem
   for (int cand = (d.ntaps == 1 ? 128 : 64); cand >= 32; cand >>= 1)
     if (d.CINP % cand == 0) { P.CC = cand; break; }
   // tall narrow tiles (W = 2: 66 x 4 halo patch) would leave a single workgroup per CU with 64-channel chunks
-  if (mode3 && d.ntaps > 1 && P.CC > 32 && (size_t)P.PP * P.CC * 4 + (size_t)2 * 32 * W3_RD * 2 > 80 * 1024) P.CC = 32;
+  if (mode3 && d.ntaps > 1 && P.CC > 32 && (size_t)P.PP * P.CC * 4 + (size_t)W3_DY_BYTES > 80 * 1024) P.CC = 32;
   BSED_CHECK_ARG(d.CINP % P.CC == 0 && d.CINP / P.CC <= 65535, "bsed_wgrad: CINP must be a multiple of 32");
   P.lgc4 = ilog2_exact(P.CC / 4);
   P.nct = P.CC / 32;
@@ -839,13 +885,13 @@ static int wgrad_prepare(const BsedWgradDesc* desc, WgradParams& P, size_t& smem
   // staged once per 64 output channels and the per-CU load rate stops being the limiter)
   P.ntw = 1;
   for (int cand = 4; cand >= 2; cand >>= 1) {
-    const size_t need = mode3 ? (size_t)P.dy_off * 4 + (size_t)2 * 32 * cand * W3_RD * 2
+    const size_t need = mode3 ? (size_t)P.dy_off * 4 + (size_t)W3_DY_BYTES * cand
                               : ((size_t)P.dy_off + IG_TILE_M * 32 * cand) * sizeof(float);
     const size_t budget = d.ntaps == 1 ? 160 * 1024 : 80 * 1024;
     const int tap_items = P.pack2 ? (d.ntaps + 1) / 2 : d.ntaps;
     if (d.NP % (32 * cand) == 0 && tap_items * P.nct * cand <= 36 && need <= budget) { P.ntw = cand; break; }
   }
-  smem = mode3 ? (size_t)P.dy_off * 4 + (size_t)2 * 32 * P.ntw * W3_RD * 2
+  smem = mode3 ? (size_t)P.dy_off * 4 + (size_t)W3_DY_BYTES * P.ntw
                : ((size_t)P.dy_off + IG_TILE_M * 32 * P.ntw) * sizeof(float);
   BSED_CHECK_ARG(smem <= 160 * 1024, "bsed_wgrad: tile needs %zu B of LDS", smem);
   const long ntiles = (long)d.NB * d.tilesH * d.tilesW;
@@ -919,16 +965,22 @@ extern "C" int bsed_wgrad(const BsedWgradDesc* desc, void* stream) {
 }
 
 
-template <int MAXS, int NW>
-static int launch_wgrad3(const WgradParams& P, dim3 grid, size_t smem, hipStream_t s) {
+template <int MAXS, int NW, bool BS>
+static int launch_wgrad3_bs(const WgradParams& P, dim3 grid, size_t smem, hipStream_t s) {
   static bool done = false;
   if (!done) {
-    BSED_HIP(hipFuncSetAttribute((const void*)wgrad3_kernel<MAXS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    BSED_HIP(hipFuncSetAttribute((const void*)wgrad3_kernel<MAXS, NW, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
-  hipLaunchKernelGGL((wgrad3_kernel<MAXS, NW>), grid, dim3(NW * 64), smem, s, P);
+  hipLaunchKernelGGL((wgrad3_kernel<MAXS, NW, BS>), grid, dim3(NW * 64), smem, s, P);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
+}
+
+template <int MAXS, int NW>
+static int launch_wgrad3(const WgradParams& P, dim3 grid, size_t smem, hipStream_t s) {
+  if (NW % (P.nct * P.ntw) == 0) return launch_wgrad3_bs<MAXS, NW, true>(P, grid, smem, s);
+  return launch_wgrad3_bs<MAXS, NW, false>(P, grid, smem, s);
 }
 
 extern "C" int bsed_wgrad3_auto_g(const BsedWgradDesc* desc) {
