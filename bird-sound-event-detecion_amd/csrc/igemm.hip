@@ -441,6 +441,7 @@ typedef short w3_bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) unsigned short w3_lds_u16;
 typedef __attribute__((address_space(3))) w3_bf16x4 w3_lds_v4;
 typedef uint32_t w3_u32x2 __attribute__((ext_vector_type(2)));
+typedef float w3_f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) w3_u32x2 w3_lds_u2;
 
 // physical 32-channel chunk of logical chunk `ch` in the row of position / patch column pc (nch = chunks per row: 1, 2
@@ -524,6 +525,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
   // its fragment is read once per K step
   const uint32_t kstep = 2 * (16 >> P.lgTW) * PW * CC;  // bytes; 16 positions = (16 / TW) tile rows (TW <= 16)
   const uint32_t bstep = 2 * 16 * DYW;
+  // the fused input affine (BN apply of the previous layer): a thread's elements all sit in one channel quad, because
+  // the thread count is a multiple of the quads per position -- loaded once, not once per element per tile
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.a_scale && cz0 + 4 * (tid & ((1 << P.lgc4) - 1)) < p.CIN) {
+    sc = *reinterpret_cast<const float4*>(p.a_scale + cz0 + 4 * (tid & ((1 << P.lgc4) - 1)));
+    sh = *reinterpret_cast<const float4*>(p.a_shift + cz0 + 4 * (tid & ((1 << P.lgc4) - 1)));
+  }
 
   for (int tile0 = blockIdx.x; tile0 < P.ntiles; tile0 += gridDim.x) {
     int tile = tile0;
@@ -561,9 +569,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
         const int e = e0 + u * NTHR;
         if (e < x_total) {
           if (p.a_scale && okv[u]) {
-            const int cg = cz0 + 4 * (e & (c4n - 1));
-            const float4 sc = *reinterpret_cast<const float4*>(p.a_scale + cg);
-            const float4 sh = *reinterpret_cast<const float4*>(p.a_shift + cg);
             v[u].x = fmaf(v[u].x, sc.x, sh.x); v[u].y = fmaf(v[u].y, sc.y, sh.y);
             v[u].z = fmaf(v[u].z, sc.z, sh.z); v[u].w = fmaf(v[u].w, sc.w, sh.w);
           }
@@ -634,6 +639,214 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
         }
       }
     }
+  }
+  const int NPo = gridDim.y * DYW;
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) {
+    if (valid[s]) {
+      const int it = wave + NW * s;
+      const int cit = it % P.nct, rr = it / P.nct;
+      const int nt = rr % P.ntw, tap = rr / P.ntw;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int ci = cz0 + cit * 32 + crow(r, lh), tp = tap;
+        if (P.pack2) {
+          const int row = crow(r, lh);
+          tp = 2 * tap + (row >> 4);
+          ci = row & 15;
+          if (tp >= p.ntaps) continue;
+        }
+        p.part[(((size_t)blockIdx.x * p.ntaps + tp) * p.CINP + ci) * NPo + n0 + nt * 32 + li] = acc[s][r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Producer / consumer form of the bf16x3 weight gradient for the multi-tap convolutions: ONE 8-wave workgroup per CU
+// with two LDS tile buffers.  Waves 0-3 (one per SIMD) only run the MFMA loop of tile t; waves 4-7 (one per SIMD) only
+// load, split and write tile t+1 into the other buffer; one barrier per tile hands the buffers over.  In
+// wgrad3_kernel the two co-resident workgroups run in phase (stage, then compute), so the staging time adds to the
+// MFMA time; here a SIMD always has one wave of each kind and the staging hides behind the matrix cores.
+// Same tiles, same products, same accumulation order as wgrad3_kernel.
+// ---------------------------------------------------------------------------------------------
+#define W3P_UX 13  // float4 of the activation patch per producer thread (256 threads): PP * CC <= 13312 elements
+#define W3P_UD 8   // float4 of the dy tile per producer thread: 128 positions x 64 channels
+
+template <int MAXS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad3p_kernel(const WgradParams P) {
+  constexpr int NTHR = 256, NW = 4, UX = W3P_UX, UD = W3P_UD;
+  const BsedWgradDesc& p = P.d;
+  extern __shared__ __align__(16) uint32_t smw[];
+  const int CC = P.CC;
+  const int cz0 = blockIdx.z * CC;
+  const int DYW = 32 * P.ntw;
+  w3_lds_u16* Xh = (w3_lds_u16*)smw;
+  w3_lds_u16* Xl = Xh + P.PP * CC;
+  w3_lds_u16* DYh = Xh + 2 * P.dy_off;
+  w3_lds_u16* DYl = DYh + IG_TILE_M * DYW;
+  const int buf_u16 = 2 * P.dy_off + 2 * IG_TILE_M * DYW;  // ushorts per tile buffer
+  const int n0 = blockIdx.y * DYW;
+  const int PW = P.PW;
+
+  if (threadIdx.x >= NTHR) {
+    // ------------------------------------------------------------------ producer waves
+    const int tid = threadIdx.x - NTHR;
+    const int c4n = 1 << P.lgc4;
+    const int x_total = P.PP * c4n;
+    const int n4n = 8 * P.ntw, lgn4 = P.ntw == 4 ? 5 : (P.ntw == 2 ? 4 : 3);
+    const int d_total = IG_TILE_M * n4n;
+    // the fused input affine (BN apply of the previous layer): a thread's elements all sit in one channel quad
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.a_scale && cz0 + 4 * (tid & (c4n - 1)) < p.CIN) {
+      sc = *reinterpret_cast<const float4*>(p.a_scale + cz0 + 4 * (tid & (c4n - 1)));
+      sh = *reinterpret_cast<const float4*>(p.a_shift + cz0 + 4 * (tid & (c4n - 1)));
+    }
+    // tile-invariant element geometry: LDS offset, offset inside the image relative to the tile origin, patch row/col
+    int xo[UX], xg[UX], xrc[UX], dyo[UD], dg[UD], drc[UD];
+#pragma unroll
+    for (int u = 0; u < UX; ++u) {
+      const int e = tid + u * NTHR;
+      const int c4 = e & (c4n - 1), pos = e >> P.lgc4;
+      const int pr = (pos * P.pw_magic) >> 20, pc = pos - pr * PW;
+      xo[u] = pos * CC + (w3_chunk(c4 >> 3, pc, P.nct) << 5) + 4 * (c4 & 7);
+      xg[u] = ((pr - p.hh) * p.W + (pc - p.hw)) * p.in_pitch + cz0 + 4 * c4;
+      xrc[u] = (e < x_total && cz0 + 4 * c4 < p.CIN) ? ((pr - p.hh) << 16) | ((pc - p.hw) & 0xffff) : (0x4000 << 16);
+    }
+#pragma unroll
+    for (int u = 0; u < UD; ++u) {
+      const int e = tid + u * NTHR;
+      const int n4 = e & (n4n - 1), mm = e >> lgn4;
+      const int r = mm >> P.lgTW, c = mm & (p.TW - 1);
+      dyo[u] = mm * DYW + (w3_chunk(n4 >> 3, mm, P.ntw) << 5) + 4 * (n4 & 7);
+      dg[u] = (r * p.W + c) * p.dy_pitch + n0 + 4 * n4;
+      drc[u] = (e < d_total && n0 + 4 * n4 < p.N) ? (r << 16) | c : (0x4000 << 16);
+    }
+    int buf = 0;
+    for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x, buf ^= 1) {
+      int t = tile;
+      const int tw_i = t % p.tilesW; t /= p.tilesW;
+      const int th_i = t % p.tilesH;
+      const int nb = t / p.tilesH;
+      const int th0 = th_i * p.TH, tw0 = tw_i * p.TW;
+      const float* inb = p.in + ((size_t)nb * p.H * p.W + (size_t)th0 * p.W + tw0) * p.in_pitch;
+      const float* dyb = p.dy + ((size_t)nb * p.H * p.W + (size_t)th0 * p.W + tw0) * p.dy_pitch;
+      w3_f32x4 vx[UX], vd[UD];  // native vectors: arrays of HIP float4 structs end up in scratch
+      uint32_t okx = 0;
+#pragma unroll
+      for (int u = 0; u < UX; ++u) {
+        const int gh_ = th0 + (xrc[u] >> 16), gw = tw0 + (int)(short)(xrc[u] & 0xffff);
+        vx[u] = w3_f32x4{0.f, 0.f, 0.f, 0.f};
+        if (gh_ >= 0 && gh_ < p.H && gw >= 0 && gw < p.W) {
+          vx[u] = *reinterpret_cast<const w3_f32x4*>(inb + xg[u]);
+          okx |= 1u << u;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UD; ++u) {
+        const int gh_ = th0 + (drc[u] >> 16), gw = tw0 + (drc[u] & 0xffff);
+        vd[u] = w3_f32x4{0.f, 0.f, 0.f, 0.f};
+        if (gh_ < p.H && gw < p.W) vd[u] = *reinterpret_cast<const w3_f32x4*>(dyb + dg[u]);
+      }
+      // (the buffer being written was last read before the previous barrier)
+      const int bo = buf * buf_u16;
+#pragma unroll
+      for (int u = 0; u < UX; ++u) {
+        if (tid + u * NTHR < x_total) {
+          float4 v = make_float4(vx[u][0], vx[u][1], vx[u][2], vx[u][3]);
+          if (p.a_scale && ((okx >> u) & 1)) {
+            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+            v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+          }
+          w3_store4(Xh, Xl, bo + xo[u], v);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UD; ++u)
+        if (tid + u * NTHR < d_total)
+          w3_store4(DYh, DYl, bo + dyo[u], make_float4(vd[u][0], vd[u][1], vd[u][2], vd[u][3]));
+      __syncthreads();
+    }
+    __syncthreads();  // pairs with the consumers' barrier after their last tile
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer waves
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int ntap_items = P.pack2 ? (p.ntaps + 1) / 2 : p.ntaps;
+  const int nitems = ntap_items * P.nct * P.ntw;
+  const int gq = (lane >> 2) & 3, gc = 4 * (lane & 3), gh = (lane >> 4) & 1;  // see wgrad3_kernel
+  const uint32_t xh0 = (uint32_t)(uintptr_t)Xh, dh0 = (uint32_t)(uintptr_t)DYh;
+  const uint32_t xlo = 2 * P.PP * CC, dlo = 2 * IG_TILE_M * DYW;
+  uint32_t xa[MAXS][2], xb[2];
+  bool valid[MAXS];
+  f32x16 acc[MAXS];
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) {
+    const int it = wave + NW * s;
+    valid[s] = it < nitems;
+    const int cit = valid[s] ? it % P.nct : 0, rr = valid[s] ? it / P.nct : 0;
+    const int nt = rr % P.ntw, tap = rr / P.ntw;
+    int tp = tap, col = 16 * gh + gc;
+    if (P.pack2) {
+      const int tb = 2 * tap + 1;
+      tp = 2 * tap;
+      if (gh && tb < p.ntaps) { tp = tb; col = gc; }
+    }
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int mk = 8 * lh + 4 * rd + gq;
+      const int pr = (mk >> P.lgTW) + p.hh + p.dh[tp], pc = (mk & (p.TW - 1)) + p.hw + p.dw[tp];
+      xa[s][rd] = xh0 + 2 * ((pr * PW + pc) * CC + (w3_chunk(cit, pc, P.nct) << 5) + col);
+      // the host only picks this kernel when all items of a wave share the dy tile (4 % (nct * ntw) == 0)
+      if (s == 0) xb[rd] = dh0 + 2 * (mk * DYW + (w3_chunk(nt, mk, P.ntw) << 5) + 16 * gh + gc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+  }
+  const uint32_t kstep = 2 * (16 >> P.lgTW) * PW * CC;
+  const uint32_t bstep = 2 * 16 * DYW;
+  __syncthreads();  // tile 0 is in buffer 0
+  int buf = 0;
+  for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x, buf ^= 1) {
+    // fragments of slot group g+1 are requested before the MFMAs of group g issue (two groups live at a time)
+    constexpr int SG = 2, NG = (MAXS + SG - 1) / SG;
+    uint32_t ko = 2 * buf * buf_u16, kb = ko;
+#pragma unroll 1
+    for (int kp = 0; kp < IG_TILE_M; kp += 16, ko += kstep, kb += bstep) {
+      w3_bf16x8 ah[2][SG], al[2][SG], bh, bl;
+#pragma unroll
+      for (int g = 0; g <= NG; ++g) {
+        if (g < NG) {
+#pragma unroll
+          for (int j = 0; j < SG; ++j) {
+            const int sl = g * SG + j;
+            if (sl < MAXS) {
+              ah[g & 1][j] = w3_frag(xa[sl][0] + ko, xa[sl][1] + ko);
+              al[g & 1][j] = w3_frag(xa[sl][0] + ko + xlo, xa[sl][1] + ko + xlo);
+              if (sl == 0) {
+                bh = w3_frag(xb[0] + kb, xb[1] + kb);
+                bl = w3_frag(xb[0] + kb + dlo, xb[1] + kb + dlo);
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (g > 0) {
+#pragma unroll
+          for (int j = 0; j < SG; ++j) {
+            const int sl = (g - 1) * SG + j;
+            if (sl < MAXS) {
+              acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[(g - 1) & 1][j], bh, acc[sl], 0, 0, 0);
+              acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[(g - 1) & 1][j], bl, acc[sl], 0, 0, 0);
+              acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[(g - 1) & 1][j], bh, acc[sl], 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    __syncthreads();
   }
   const int NPo = gridDim.y * DYW;
 #pragma unroll
@@ -983,12 +1196,32 @@ static int launch_wgrad3(const WgradParams& P, dim3 grid, size_t smem, hipStream
   return launch_wgrad3_bs<MAXS, NW, false>(P, grid, smem, s);
 }
 
+template <int MAXS>
+static int launch_wgrad3p(const WgradParams& P, dim3 grid, size_t smem, hipStream_t s) {
+  static bool done = false;
+  if (!done) {
+    BSED_HIP(hipFuncSetAttribute((const void*)wgrad3p_kernel<MAXS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+  }
+  hipLaunchKernelGGL((wgrad3p_kernel<MAXS>), grid, dim3(512), 2 * smem, s, P);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+// the pipelined kernel takes the multi-tap shapes whose two tile buffers fit in LDS and whose per-thread prefetch fits
+// its register arrays; everything else (1-tap forms, tall narrow patches) stays on wgrad3_kernel
+static bool wgrad3_pipelined(const WgradParams& P, size_t smem) {
+  const int nitems = (P.pack2 ? (P.d.ntaps + 1) / 2 : P.d.ntaps) * P.nct * P.ntw;
+  return P.d.ntaps > 1 && P.d.H < 16384 && P.d.W < 16384 && 2 * smem <= 160 * 1024 && 4 % (P.nct * P.ntw) == 0 && nitems > 8 && nitems <= 36 &&
+         P.PP * (P.CC / 4) <= W3P_UX * 256 && IG_TILE_M * 8 * P.ntw <= W3P_UD * 256 && !getenv("BSED_WGRAD3_NOPIPE");
+}
+
 extern "C" int bsed_wgrad3_auto_g(const BsedWgradDesc* desc) {
   WgradParams P;
   size_t smem;
   dim3 gyz;
   if (wgrad_prepare(desc, P, smem, gyz, 1) != BSED_OK) return -1;
-  const long slots = smem <= 80 * 1024 ? 512 : 256;
+  const long slots = wgrad3_pipelined(P, smem) ? 256 : smem <= 80 * 1024 ? 512 : 256;
   const long want = std::max<long>(1, slots / ((long)gyz.y * gyz.z));
   return (int)std::max<long>(1, std::min<long>(want, P.ntiles));
 }
@@ -998,7 +1231,8 @@ extern "C" int bsed_wgrad3_variant(const BsedWgradDesc* desc) {
   size_t smem;
   dim3 gyz;
   if (wgrad_prepare(desc, P, smem, gyz, 1) != BSED_OK) return -1;
-  return wgrad_variant(P);
+  const int v = wgrad_variant(P);
+  return wgrad3_pipelined(P, smem) ? (v / 16) * 16 + 1 : v;  // NW field 1 = wgrad3p_kernel<MAXS>
 }
 
 extern "C" int bsed_wgrad3(const BsedWgradDesc* desc, void* stream) {
@@ -1013,6 +1247,11 @@ extern "C" int bsed_wgrad3(const BsedWgradDesc* desc, void* stream) {
   dim3 grid((unsigned)d.G, gyz.y, gyz.z);
   hipStream_t s = (hipStream_t)stream;
   const int v = wgrad_variant(P), maxs = v / 16, nw = v % 16;
+  if (wgrad3_pipelined(P, smem)) {
+    if (maxs == 3) return launch_wgrad3p<3>(P, grid, smem, s);
+    if (maxs == 5) return launch_wgrad3p<5>(P, grid, smem, s);
+    return launch_wgrad3p<9>(P, grid, smem, s);
+  }
   if (nw == 8) {
     if (maxs == 2) return launch_wgrad3<2, 8>(P, grid, smem, s);
     if (maxs == 3) return launch_wgrad3<3, 8>(P, grid, smem, s);

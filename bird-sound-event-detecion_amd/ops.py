@@ -276,7 +276,8 @@ def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=Non
     part = torch.empty((G, len(taps), CINP, NP), device=inp.device, dtype=torch.float32)
     d.part, d.G = _p(part), G
     var = getattr(L.lib(), f"bsed_wgrad{sfx}_variant")(ctypes.byref(d))
-    _launch((f"wgrad{sfx}_kernel<{var // 16}, {var % 16}>", len(taps), CIN, N, H, W),
+    kname = f"wgrad3p_kernel<{var // 16}>" if var % 16 == 1 else f"wgrad{sfx}_kernel<{var // 16}, {var % 16}>"
+    _launch((kname, len(taps), CIN, N, H, W),
             2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call(f"bsed_wgrad{sfx}", ctypes.byref(d), L.stream()))
     return part, G, CINP, NP
 
