@@ -16,6 +16,7 @@ region) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a b
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -249,7 +250,7 @@ def main():
         gbs = bytes_total / (total_ms * 1e-3) / 1e9
         # kernels named *3_kernel / *3n_kernel run split-fp32 operands on the bf16 matrix cores: 3 bf16 MFMAs per
         # product, so their ceiling in algorithmic (fp32-equivalent) FLOP/s is the dense bf16 peak / 3
-        split = "3_kernel" in name or "3n_kernel" in name or "3p_kernel" in name
+        split = re.search(r"3[a-z]?_kernel", name) is not None
         peak_tf = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS
         # which roof bounds this kernel: its arithmetic intensity against the ridge point of ITS matrix-core ceiling
         intensity = flops_total / max(bytes_total, 1.0)

@@ -1222,7 +1222,12 @@ extern "C" int bsed_wgrad3_auto_g(const BsedWgradDesc* desc) {
   dim3 gyz;
   if (wgrad_prepare(desc, P, smem, gyz, 1) != BSED_OK) return -1;
   const long slots = wgrad3_pipelined(P, smem) ? 256 : smem <= 80 * 1024 ? 512 : 256;
-  const long want = std::max<long>(1, slots / ((long)gyz.y * gyz.z));
+  long want = std::max<long>(1, slots / ((long)gyz.y * gyz.z));
+  // XCD affinity: workgroup (x, y, z) has linear id x + G * (y + gy * z) and lands on XCD id % 8.  The gy * gz
+  // workgroups of one tile sequence x read the same activation / dy tiles at about the same time; with G a multiple of
+  // 8 they share an XCD, hence its L2, and the re-reads stop going to HBM (BSED_WGRAD3_G8=0 disables, for A/B runs)
+  const char* g8 = getenv("BSED_WGRAD3_G8");
+  if (gyz.y * gyz.z > 1 && (want % 8) * 16 <= want && !(g8 && g8[0] == '0')) want -= want % 8;  // <= 6 % fewer workgroups
   return (int)std::max<long>(1, std::min<long>(want, P.ntiles));
 }
 
@@ -1232,7 +1237,8 @@ extern "C" int bsed_wgrad3_variant(const BsedWgradDesc* desc) {
   dim3 gyz;
   if (wgrad_prepare(desc, P, smem, gyz, 1) != BSED_OK) return -1;
   const int v = wgrad_variant(P);
-  return wgrad3_pipelined(P, smem) ? (v / 16) * 16 + 1 : v;  // NW field 1 = wgrad3p_kernel<MAXS>
+  if (wgrad3_pipelined(P, smem)) return (v / 16) * 16 + 1;  // NW field 1 = wgrad3p_kernel<MAXS>
+  return v | (((v % 16) % (P.nct * P.ntw) == 0) ? 1 << 12 : 0);  // bit 12 = the BS template argument
 }
 
 extern "C" int bsed_wgrad3(const BsedWgradDesc* desc, void* stream) {

@@ -242,7 +242,9 @@ def igemm3(inp, w3, N, NB, H, W, CIN, taps, bias=None, epilogue=EPI_PLAIN):
         d.dh[i], d.dw[i] = a, b
     d.ph = d.pw = 1; d.Hp, d.Wp = H, W
     d.epilogue = epilogue
-    _launch((f"igemm3_kernel<{bn}, {1 if epilogue == EPI_STATS else 0}, {rb}>", len(taps), CIN, N, H, W),
+    need = ((TH + 2 * d.hh) * (TW + 2 * d.hw) * 8 + 255) // 256        # float4 patch elements per thread (launch_i3)
+    pv = 12 if rb == 2 or need > 9 else (9 if need > 6 else 6)
+    _launch((f"igemm3_kernel<{bn}, {1 if epilogue == EPI_STATS else 0}, {rb}, {pv}>", len(taps), CIN, N, H, W),
             2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call("bsed_igemm3", ctypes.byref(d), L.stream()))
     return out, stats
 
@@ -276,7 +278,14 @@ def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=Non
     part = torch.empty((G, len(taps), CINP, NP), device=inp.device, dtype=torch.float32)
     d.part, d.G = _p(part), G
     var = getattr(L.lib(), f"bsed_wgrad{sfx}_variant")(ctypes.byref(d))
-    kname = f"wgrad3p_kernel<{var // 16}>" if var % 16 == 1 else f"wgrad{sfx}_kernel<{var // 16}, {var % 16}>"
+    # labels = the template instances as rocprofv3 prints them (bench.py joins the two by name)
+    bs, var = var >> 12, var & 0xfff
+    if var % 16 == 1:
+        kname = f"wgrad3p_kernel<{var // 16}>"
+    elif sfx:
+        kname = f"wgrad3_kernel<{var // 16}, {var % 16}, {'true' if bs else 'false'}>"
+    else:
+        kname = f"wgrad_kernel<{var // 16}, {var % 16}>"
     _launch((kname, len(taps), CIN, N, H, W),
             2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call(f"bsed_wgrad{sfx}", ctypes.byref(d), L.stream()))
     return part, G, CINP, NP
