@@ -297,3 +297,43 @@ def test_dgrad_cin32_split_fp32_matches_torch(B, H, W, N):
     dx, _ = ops.igemm3s(dy, wt, N, B, H, W, flipped)
     ref = torch.nn.functional.conv_transpose2d(dy.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
     assert float((dx.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,cin,co,affine", [
+    (2, 45, 64, 16, 32, False),     # conv1: two taps share one MFMA tile (pack2)
+    (2, 37, 32, 32, 64, True),      # 32-channel chunks, producer/consumer kernel, 5 slots
+    (3, 50, 16, 64, 128, True),     # 9 slots, producer/consumer kernel, 16-wide tiles
+    (2, 61, 8, 128, 128, False),    # 9 slots, two channel chunks (grid.z = 2)
+    (2, 70, 4, 128, 128, True),     # tall 34 x 6 patch
+    (2, 130, 2, 128, 128, False),   # 66 x 4 patch: 32-channel chunks
+    (1, 19, 16, 64, 64, False),     # one ragged tile row only
+])
+def test_conv3x3_weight_gradient_bf16x3_matches_fp64_reference(B, H, W, cin, co, affine, monkeypatch):
+    """dW of a 3x3 convolution from the split-fp32 weight-gradient kernels (transposing LDS reads; the
+    producer/consumer form where it applies and the single-buffer form forced through BSED_WGRAD3_NOPIPE), with and
+    without the fused per-channel affine on the staged activations (BatchNorm apply of the previous layer)."""
+    from bsed_amd import ops
+    rng = np.random.default_rng(B * 100 + H + W)
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, W)).astype(np.float32))
+    dy = torch.from_numpy(rng.standard_normal((B, co, H, W)).astype(np.float32))
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, cin).astype(np.float32))
+    sh = torch.from_numpy(rng.standard_normal(cin).astype(np.float32))
+    xin = x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) if affine else x.double()
+    ref = torch.nn.grad.conv2d_weight(xin, (co, cin, 3, 3), dy.double(), padding=1)
+    xg, dyg = _nhwc(x).cuda(), _nhwc(dy).cuda()
+    kw = dict(a_scale=sc.cuda(), a_shift=sh.cuda()) if affine else {}
+    got = {}
+    for nopipe in ("", "1"):
+        if nopipe:
+            monkeypatch.setenv("BSED_WGRAD3_NOPIPE", "1")
+        else:
+            monkeypatch.delenv("BSED_WGRAD3_NOPIPE", raising=False)
+        part, G, KP, NP = ops.wgrad(xg, dyg, B, H, W, cin, co, taps=ops.TAPS3x3, mode="bf16x3", **kw)
+        dw = torch.zeros((co, cin, 3, 3), device="cuda")
+        ops.reduce_partials(part, G, 9, KP, NP, cin, co, dw, 1, 9, cin * 9)
+        got[nopipe] = dw.cpu()
+        err = float((dw.cpu().double() - ref).norm() / ref.norm())
+        assert err < 4e-5, (nopipe, err)
+    # both forms build the same products in the same order; they differ only in how many partial slabs are summed
+    np.testing.assert_allclose(got[""].numpy(), got["1"].numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
