@@ -58,6 +58,8 @@ class Clip_Discriminator(_FlatModule):
             pspecs += [(f"bn_{k}.weight", (D_CH[k],)), (f"bn_{k}.bias", (D_CH[k],))]
             bspecs += [(f"bn_{k}.running_mean", (D_CH[k],)), (f"bn_{k}.running_var", (D_CH[k],))]
         self._build(pspecs, bspecs, device)
+        import os
+        self.conv_mode = os.environ.get("BSED_CONV_MODE", "bf16x3")       # as models.CRNN: "fp32" = fp32 matrix cores
         self.nbt = torch.zeros(5, device=device, dtype=torch.int64)
         for k in range(1, 6):
             self.P(f"bn_{k}").register_buffer("num_batches_tracked", self.nbt[k - 1])
@@ -127,8 +129,14 @@ class Clip_Discriminator(_FlatModule):
             wpk, CP = self._fwd_weight(k)
             col, Ho, Wo, K = _im2col(act, scale, shift, N, Hi, Wi, cin, CP)
             M = N * Ho * Wo
-            y, stats = ops.igemm(col, wpk, co, 1, M, 1, K, bias=self.P(f"conv_{k}.bias"),
-                                 epilogue=ops.EPI_STATS if train else ops.EPI_PLAIN)
+            epi = ops.EPI_STATS if train else ops.EPI_PLAIN
+            if self.conv_mode == "bf16x3" and K % 32 == 0:
+                # split-fp32 operands on the bf16 matrix cores (the 9x larger col matrix makes these GEMMs HBM-bound:
+                # what counts is that the kernel streams, which the fp32-core GEMM does not at K = 1152)
+                w3 = ops.pack_weight3(wpk, 1, K, co, 0, wpk.shape[2], 1)
+                y, stats = ops.igemm3(col, w3, co, 1, M, 1, K, ((0, 0),), bias=self.P(f"conv_{k}.bias"), epilogue=epi)
+            else:
+                y, stats = ops.igemm(col, wpk, co, 1, M, 1, K, bias=self.P(f"conv_{k}.bias"), epilogue=epi)
             bn = self.P(f"bn_{k}")
             if train:
                 mean, invstd, scale, shift = ops.bn_finalize(stats, co, float(M), D_EPS, D_MOM, bn.weight, bn.bias,
@@ -187,7 +195,11 @@ class Clip_Discriminator(_FlatModule):
                 dyp = torch.zeros((l["M"], cop), device=dy.device, dtype=torch.float32)
                 dyp[:, :co] = dy
                 dy = dyp
-            dcol, _ = ops.igemm(dy, wT, K, 1, l["M"], 1, cop)
+            if self.conv_mode == "bf16x3" and cop % 32 == 0:
+                w3 = ops.pack_weight3(wT, 1, cop, K, 0, wT.shape[2], 1)
+                dcol, _ = ops.igemm3(dy, w3, K, 1, l["M"], 1, cop, ((0, 0),))
+            else:
+                dcol, _ = ops.igemm(dy, wT, K, 1, l["M"], 1, cop)
             if k > 1:
                 p = lay[k - 2]
                 g, stats = _col2im(dcol, p["y"], p["scale"], p["shift"], N, l["Hi"], l["Wi"], cin, l["CP"])
