@@ -143,8 +143,12 @@ int bsed_wgrad(const BsedWgradDesc* desc /*host*/, void* stream);
 int bsed_wgrad_auto_g(const BsedWgradDesc* desc /*host*/);
 /* template instance bsed_wgrad launches for this shape, as MAXS*16 + NW (labels profiles and bench lines) */
 int bsed_wgrad_variant(const BsedWgradDesc* desc /*host*/);
-/* the same contraction with split-fp32 operands on the bf16 matrix cores (bf16x3, ~1e-5 relative): dy staged
- * transposed, activation fragments gathered per tap.  Same descriptor, same partial-slab layout. */
+/* the same contraction with split-fp32 operands on the bf16 matrix cores (bf16x3, ~1e-5 relative): both tiles stay
+ * position-major in LDS (bf16 hi / lo planes) and the operand fragments come out of transposing LDS reads; multi-tap
+ * shapes whose two tile buffers fit in LDS run the producer/consumer kernel (wgrad3p_kernel).  Same descriptor, same
+ * partial-slab layout; G must come from bsed_wgrad3_auto_g (it differs between the two kernels).
+ * bsed_wgrad3_variant: MAXS*16 + NW, NW == 1 meaning wgrad3p_kernel<MAXS>; bit 12 = the BS template argument of
+ * wgrad3_kernel<MAXS, NW, BS> (labels only).  BSED_WGRAD3_NOPIPE=1 in the environment forces wgrad3_kernel (A/B runs). */
 int bsed_wgrad3(const BsedWgradDesc* desc /*host*/, void* stream);
 int bsed_wgrad3_auto_g(const BsedWgradDesc* desc /*host*/);
 int bsed_wgrad3_variant(const BsedWgradDesc* desc /*host*/);
