@@ -294,7 +294,7 @@ class _GRL(torch.autograd.Function):
 def domain_loss(disc, f_s, f_t, coeff):
     """cdan_frame.py:89-119 as actually executed: BCE(D(GRL(cat(f_s,f_t))), [1..,0..])."""
     d = disc(_GRL.apply(torch.cat((f_s, f_t), 0), coeff)).squeeze()
-    lab = torch.cat((torch.ones(f_s.size(0)), torch.zeros(f_t.size(0))))
+    lab = torch.cat((torch.ones(f_s.size(0)), torch.zeros(f_t.size(0)))).to(d.dtype)
     return F.binary_cross_entropy(d, lab)
 
 

@@ -148,3 +148,97 @@ def test_split_fp32_and_fp32_modes_agree_on_odd_shapes(Bq, Tq, Fq, seed):
         if err > 3e-4 and float(b.norm()) > 1e-7:
             bad.append((k, err))
     assert not bad, bad
+
+
+def test_discriminator_gradients_vs_fp64_oracle_at_full_size():
+    """Clip_Discriminator at the BASELINE shape (12 + 12 clips x 216 frames x 256 features) against the oracle run in
+    float64 (seconds on the CPU at this size).  Loss to 1e-6.  The gradients pass through four LeakyReLU masks: a
+    forward rounding error eps flips ~eps of the mask elements, so the gradient error goes like sqrt(eps) whatever the
+    implementation -- measured 6e-4 for the fp32-core GEMMs (the default) and 8e-3 for the split-fp32 ones; the
+    bounds below are those with 3x head-room.  The default mode must also be bitwise repeatable."""
+    from bsed_amd.disc import Clip_Discriminator
+    rng = np.random.default_rng(31)
+    fn = rng.standard_normal((B, T // 4, 256)).astype(np.float32)
+    torch.manual_seed(5)
+    ref = Clip_Discriminator()
+    assert ref.conv_mode == "fp32"
+    od = co.Clip_Discriminator().double()
+    od.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in ref.state_dict().items()})
+    od.train()
+    x = torch.from_numpy(fn).double().requires_grad_()
+    loss_ref = co.domain_loss(od, x[:B // 2], x[B // 2:], 0.37)
+    loss_ref.backward()
+    f = torch.from_numpy(fn).cuda()
+    runs = []
+    for mode, tol in (("fp32", 2e-3), ("fp32", 2e-3), ("bf16x3", 2.5e-2)):
+        disc = Clip_Discriminator()
+        disc.load_state_dict(ref.state_dict())
+        disc.conv_mode = mode
+        disc.train(); disc.zero_grad()
+        d, ctx = disc.run_forward(f, n_source=B // 2)
+        df = disc.run_backward(ctx, 0.37)
+        loss = float(ctx["lossp"][:, 0, 0].sum() / B)
+        assert abs(loss - float(loss_ref)) < 1e-6 * float(loss_ref), (mode, loss, float(loss_ref))
+        assert float((df.cpu().double() - x.grad).norm()) < tol * float(x.grad.norm()), mode
+        grads = {k: p.grad.clone() for k, p in disc.named_parameters()}
+        for k, p in od.named_parameters():
+            if k.startswith("conv_") and k.endswith("bias"):
+                continue  # zero under train-mode BatchNorm
+            assert float((grads[k].cpu().double() - p.grad).norm()) <= tol * float(p.grad.norm()) + 1e-12, (mode, k)
+        runs.append((loss, df.clone(), grads))
+    (l0, d0, g0), (l1, d1, g1) = runs[0], runs[1]
+    assert l0 == l1 and torch.equal(d0, d1) and all(torch.equal(g0[k], g1[k]) for k in g0)
+
+
+def test_mean_teacher_and_adversarial_steps_run_from_waveforms_at_full_size():
+    """The two other BASELINE step kinds on raw 10 s waveforms (bench.py --mode mt / ada at the reference's batch of 24):
+    finite losses, every gradient finite, the teacher moves by exactly (1 - alpha_t) of the student/teacher gap, and
+    the adversarial step with a discriminator whose output layer is zeroed leaves the class losses where the plain
+    step puts them (the domain loss then carries no gradient into the features)."""
+    from bsed_amd.disc import Clip_Discriminator, ConditionalDomainAdversarialLoss
+    from bsed_amd.engine import FlatAdam, FlatSGD, SEDTrainer
+    from bsed_amd.features import MelConfig, MelFrontEnd
+    from bsed_amd.models import CRNN, Predictor
+    sr, n = 22050, 220500
+    g = torch.Generator(device="cuda").manual_seed(9)
+    wav = torch.randn(B, n, device="cuda", generator=g) * 0.1
+    fe = MelFrontEnd(MelConfig(sr=sr))
+    Tp = fe.num_frames(n) // 4
+    y = torch.from_numpy(seeded.strong_targets(14, B // 2, Tp)).cuda()
+    yw = y.max(1)[0].contiguous()
+    # ---- mean teacher
+    crnn, pred = _models(0.5)
+    kw = dict(co.CRNN_KWARGS); kw["dropout"] = 0.5
+    ema_c, ema_p = CRNN(**kw), Predictor(**co.PREDICTOR_KWARGS)
+    ema_c.load_state_dict(crnn.state_dict()); ema_p.load_state_dict(pred.state_dict())
+    tr = SEDTrainer(crnn, pred, ema_c, ema_p, optimizer=FlatAdam([crnn, pred], lr=1e-3), frontend=fe, seed=3)
+    before = crnn.flat.clone()
+    out = tr.train_step(wav[:B // 2].contiguous(), y, wav[B // 2:].contiguous(), yw, from_wave=True)
+    loss = SEDTrainer.loss_value(out)
+    assert np.isfinite(loss) and loss > 0
+    assert bool(torch.isfinite(crnn.flat_grad).all()) and bool(torch.isfinite(pred.flat_grad).all())
+    # reference update_ema_variables: alpha = min(1 - 1/(step+1), 0.999) = 0.5 at global_step 1; the teacher started equal
+    # to the student's OLD weights, so after the step it sits halfway between them and the new ones
+    want = 0.5 * before + 0.5 * crnn.flat
+    assert float((ema_c.flat - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-9
+    # ---- adversarial, discriminator output layer zeroed
+    losses = []
+    for adv in (False, True):
+        crnn, pred = _models(0.5)
+        extra = {}
+        if adv:
+            disc = Clip_Discriminator()
+            with torch.no_grad():
+                disc.P("dense_d").weight.zero_(); disc.P("dense_d").bias.zero_()
+            extra = dict(domain_loss=ConditionalDomainAdversarialLoss(disc),
+                         optimizer_d=FlatSGD([disc], lr=0.0, momentum=0.0, weight_decay=0.0))
+        tr = SEDTrainer(crnn, pred, optimizer=FlatAdam([crnn, pred], lr=1e-3), frontend=fe, seed=3, **extra)
+        if adv:
+            out = tr.train_step(wav[:B // 2].contiguous(), y, wav[B // 2:].contiguous(), None, from_wave=True)
+            assert abs(float(out["domain"]) - np.log(2.0)) < 1e-5      # BCE of sigmoid(0) against either label
+        else:
+            out = tr.train_step(wav[:B // 2].contiguous(), y, from_wave=True)
+        losses.append((out["syn"].double().sum(0).cpu(), crnn.flat_grad.clone()))
+    (l0, g0), (l1, g1) = losses
+    assert torch.allclose(l0, l1, rtol=1e-6, atol=1e-7)
+    assert float((g0 - g1).abs().max()) <= 1e-6 * float(g0.abs().max())
