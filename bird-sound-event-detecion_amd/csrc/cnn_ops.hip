@@ -46,14 +46,26 @@ __global__ __launch_bounds__(256) void conv0_fwd_kernel(const float* __restrict_
       for (int t = 0; t < 9; ++t) a = fmaf(in9[t], ws[c * 9 + t], a);
       out[c] = a;
     }
-    float4* dst = reinterpret_cast<float4*>(y + ((size_t)nb * per_img + pos) * CO);
+  }
+  // The outputs go through LDS so that a store instruction writes 1 KB of consecutive addresses (lane = consecutive
+  // float4 of the workgroup's [256 positions][CO] block) instead of 16 bytes out of every thread's CO*4-byte row.
 #pragma unroll
-    for (int c = 0; c < CO; c += 4) dst[c / 4] = make_float4(out[c], out[c + 1], out[c + 2], out[c + 3]);
+  for (int c = 0; c < CO; ++c) sv[tid * (CO + 1) + c] = out[c];  // zeros for out-of-range positions
+  __syncthreads();
+  {
+    const long pos0 = (long)blockIdx.x * 256;
+    float4* dst = reinterpret_cast<float4*>(y + ((size_t)nb * per_img + pos0) * CO);
+    constexpr int Q = CO / 4;  // float4 per position
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      const int e = tid + 256 * k, p = e / Q, q = e % Q;
+      if (pos0 + p < per_img) {
+        const float* r = sv + p * (CO + 1) + 4 * q;
+        dst[e] = make_float4(r[0], r[1], r[2], r[3]);
+      }
+    }
   }
   if (stats) {
-#pragma unroll
-    for (int c = 0; c < CO; ++c) sv[tid * (CO + 1) + c] = out[c];  // zeros for out-of-range positions
-    __syncthreads();
     // thread (c, g): channel c over positions g*PG .. g*PG+PG-1
     constexpr int NG = 256 / CO;   // groups
     constexpr int PG = 256 / NG;   // positions per group (= CO)
