@@ -212,7 +212,8 @@ def igemm3s(inp, wtab, N, NB, H, W, taps, bias=None, epilogue=EPI_PLAIN):
         d.dh[i], d.dw[i] = a, b
     d.ph = d.pw = 1; d.Hp, d.Wp = H, W
     d.epilogue = epilogue
-    _launch((f"igemm3s_kernel<{1 if epilogue == EPI_STATS else 0}, {len(taps)}, {CIN // 16}>", len(taps), CIN, N, H, W),
+    nv = 16 if N <= 16 and N % 4 == 0 else 32                      # transposed epilogue (bsed_igemm3s)
+    _launch((f"igemm3s_kernel<{1 if epilogue == EPI_STATS else 0}, {len(taps)}, {CIN // 16}, {nv}>", len(taps), CIN, N, H, W),
             2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call("bsed_igemm3s", ctypes.byref(d), _i(G), L.stream()))
     return out, stats
 
