@@ -598,6 +598,13 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
   float* s_sc = reinterpret_cast<float*>(WF + NT * KS * 2 * 64);
   float* s_sh = s_sc + C;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  // C <= 64: the wave's 32 position rows of y are staged once, as whole lines (float4 per lane, 1 KB of consecutive
+  // addresses per load instruction), into a wave-private LDS image that serves both reads of y -- the A fragments
+  // (8 consecutive channels of the lane's position: 16-byte pieces of 32 different lines per instruction when read
+  // straight from global) and the gate input of the epilogue.  No workgroup barrier: the image is private to the wave.
+  constexpr bool STAGE = C <= 64;
+  constexpr int YROW = C + 4;  // floats per staged row: (C + 4) * 4 bytes = odd multiple of 16
+  float* Ys = s_sh + C + wave * 32 * YROW;
 
   build_weight_frags<C>(P.w, WF, nullptr, tid);
   for (int i = tid; i < C; i += G3_THREADS) { s_sc[i] = P.scale[i]; s_sh[i] = P.shift[i]; }
@@ -628,7 +635,44 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
     f32x16 acc[NT];
     {
       bf16x8 a_hi[KS], a_lo[KS];
-      load_a_frags<C>(P, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
+      if constexpr (STAGE) {
+        constexpr int Q = C / 4, NL = 32 * Q / 64;  // float4 per row, loads per lane
+        f32x4 raw[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+          const int e = lane + 64 * k, pr = e / Q, q = e % Q;
+          const int mm = wave * 32 + pr;
+          const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (TW - 1));
+          raw[k] = gh < P.H ? *reinterpret_cast<const f32x4*>(P.y + (((size_t)nb * P.H + gh) * P.W + gw) * C + 4 * q)
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous tile's reads of the image are done
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+          const int e = lane + 64 * k;
+          *reinterpret_cast<f32x4*>(Ys + (e / Q) * YROW + 4 * (e % Q)) = raw[k];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // image complete before other lanes' rows are read
+        const int mA = wave * 32 + li;
+        const float okf = th0 + (mA >> P.lgTW) < P.H ? 1.0f : 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const f32x4 r0 = *reinterpret_cast<const f32x4*>(Ys + li * YROW + 16 * ks + 8 * lh);
+          const f32x4 r1 = *reinterpret_cast<const f32x4*>(Ys + li * YROW + 16 * ks + 8 * lh + 4);
+          const float4 s0 = *reinterpret_cast<const float4*>(s_sc + 16 * ks + 8 * lh);
+          const float4 s1 = *reinterpret_cast<const float4*>(s_sc + 16 * ks + 8 * lh + 4);
+          const float4 h0 = *reinterpret_cast<const float4*>(s_sh + 16 * ks + 8 * lh);
+          const float4 h1 = *reinterpret_cast<const float4*>(s_sh + 16 * ks + 8 * lh + 4);
+          float v[8];
+          v[0] = fmaf(r0[0], s0.x, h0.x) * okf; v[1] = fmaf(r0[1], s0.y, h0.y) * okf;
+          v[2] = fmaf(r0[2], s0.z, h0.z) * okf; v[3] = fmaf(r0[3], s0.w, h0.w) * okf;
+          v[4] = fmaf(r1[0], s1.x, h1.x) * okf; v[5] = fmaf(r1[1], s1.y, h1.y) * okf;
+          v[6] = fmaf(r1[2], s1.z, h1.z) * okf; v[7] = fmaf(r1[3], s1.w, h1.w) * okf;
+          split_pack8(v, a_hi[ks], a_lo[ks]);
+        }
+      } else {
+        load_a_frags<C>(P, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
+      }
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -657,7 +701,8 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
         mk[rr] = gh < P.H ? 1.0f : 0.0f;
         posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) yv[rr][j] = P.y[posv[rr] + 32 * j];
+        for (int j = 0; j < NT; ++j)
+          yv[rr][j] = STAGE ? Ys[(8 * rg + lhv + rr) * YROW + 32 * j + li] : P.y[posv[rr] + 32 * j];
       }
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
@@ -718,7 +763,8 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
 template <int C>
 static int launch_glu_fwd3(const Glu3Params& P, int G, hipStream_t s) {
   constexpr int NT = C / 32, KS = C / 16;
-  const size_t smem = (size_t)NT * KS * 2 * 64 * 16 + 2 * C * sizeof(float);
+  const size_t smem = (size_t)NT * KS * 2 * 64 * 16 + 2 * C * sizeof(float) +
+                      (C <= 64 ? (size_t)4 * 32 * (C + 4) * sizeof(float) : 0);  // + the waves' staged y rows
   static bool done = false;
   if (!done) {
     BSED_HIP(hipFuncSetAttribute((const void*)glu_fwd3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
