@@ -15,6 +15,26 @@
 #define HD_FR 32       // frames per chunk
 #define HD_THREADS 256
 
+// rows of HD_K floats, global -> LDS rows of HD_K + 1: all of a thread's float4 loads are issued before the first LDS
+// store (a load-then-store loop of scalars waits out one memory latency per element: 32 per chunk, ~160 us per clip)
+template <int NROWS>
+__device__ __forceinline__ void head_stage_rows(float* dst, const float* __restrict__ src, int valid_rows, int tid) {
+  constexpr int NV = NROWS * (HD_K / 4) / HD_THREADS;  // float4 per thread
+  static_assert(NROWS * (HD_K / 4) % HD_THREADS == 0, "rows must tile the workgroup");
+  float4 v[NV];
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int e = tid + u * HD_THREADS, r = e / (HD_K / 4), q = e % (HD_K / 4);
+    v[u] = r < valid_rows ? *reinterpret_cast<const float4*>(src + (size_t)r * HD_K + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int e = tid + u * HD_THREADS, r = e / (HD_K / 4), q = e % (HD_K / 4);
+    float* d = dst + r * (HD_K + 1) + 4 * q;
+    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+  }
+}
+
 // logits for a chunk of frames: lg[f][0..C) dense head, lg[f][C..2C) softmax head
 template <int C>
 __device__ __forceinline__ void head_logits(const float* xs /*[HD_FR][HD_K+1]*/, const float* ws /*[2C][HD_K+1]*/,
@@ -37,7 +57,8 @@ template <int C>
 __global__ __launch_bounds__(HD_THREADS) void head_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w /*(2C,256): dense rows then softmax rows*/,
     const float* __restrict__ b /*(2C)*/, float* __restrict__ strong, float* __restrict__ sof_raw,
-    float* __restrict__ weak, float* __restrict__ den_out, int T, int attention) {
+    float* __restrict__ weak, float* __restrict__ den_out, float* __restrict__ part /*(B,S,2,C), S = gridDim.y > 1*/,
+    int T, int attention) {
   extern __shared__ __align__(16) float smem[];
   float* ws = smem;                          // [2C][257]
   float* xs = ws + 2 * C * (HD_K + 1);       // [32][257]
@@ -46,15 +67,17 @@ __global__ __launch_bounds__(HD_THREADS) void head_fwd_kernel(
   float* sS = bsm + 2 * C;                   // [32][C]
   float* sA = sS + HD_FR * C;                // [32][C]
   const int tid = threadIdx.x, b_ = blockIdx.x;
-  for (int i = tid; i < 2 * C * HD_K; i += HD_THREADS) ws[(i / HD_K) * (HD_K + 1) + (i % HD_K)] = w[i];
+  head_stage_rows<2 * C>(ws, w, 2 * C, tid);
   if (tid < 2 * C) bsm[tid] = b[tid];
   float num = 0.f, den = 0.f;
-  for (int f0 = 0; f0 < T; f0 += HD_FR) {
+  // the clip's frames are split over gridDim.y workgroups (whole 32-frame chunks each): one workgroup per clip left
+  // the chip at one 4-wave workgroup per CU with ~30 barriers in a row
+  const int S = gridDim.y, sp = blockIdx.y;
+  const int cps = ((T + HD_FR - 1) / HD_FR + S - 1) / S;
+  const int f_lo = sp * cps * HD_FR, f_hi = min(T, (sp + 1) * cps * HD_FR);
+  for (int f0 = f_lo; f0 < f_hi; f0 += HD_FR) {
     __syncthreads();
-    for (int i = tid; i < HD_FR * HD_K; i += HD_THREADS) {
-      const int f = i / HD_K, k = i % HD_K;
-      xs[f * (HD_K + 1) + k] = (f0 + f < T) ? x[((size_t)b_ * T + f0 + f) * HD_K + k] : 0.f;
-    }
+    head_stage_rows<HD_FR>(xs, x + ((size_t)b_ * T + f0) * HD_K, T - f0, tid);
     __syncthreads();
     head_logits<C>(xs, ws, bsm, lg, tid);
     __syncthreads();
@@ -87,9 +110,29 @@ __global__ __launch_bounds__(HD_THREADS) void head_fwd_kernel(
     }
   }
   if (tid < C) {
-    weak[(size_t)b_ * C + tid] = num / den;
-    den_out[(size_t)b_ * C + tid] = den;
+    if (S == 1) {
+      weak[(size_t)b_ * C + tid] = num / den;
+      den_out[(size_t)b_ * C + tid] = den;
+    } else {
+      part[(((size_t)b_ * S + sp) * 2 + 0) * C + tid] = num;
+      part[(((size_t)b_ * S + sp) * 2 + 1) * C + tid] = den;
+    }
   }
+}
+
+// weak = sum_s num / sum_s den over the time splits of head_fwd_kernel (fixed order: repeatable)
+__global__ void head_weak_kernel(const float* __restrict__ part, float* __restrict__ weak, float* __restrict__ den_out,
+                                 int B, int S, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b_ = i / C, c = i % C;
+  float num = 0.f, den = 0.f;
+  for (int s = 0; s < S; ++s) {
+    num += part[(((size_t)b_ * S + s) * 2 + 0) * C + c];
+    den += part[(((size_t)b_ * S + s) * 2 + 1) * C + c];
+  }
+  weak[i] = num / den;
+  den_out[i] = den;
 }
 
 // BCE element (PyTorch semantics): value with log clamped at -100
@@ -117,7 +160,12 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_kernel(
   float* dn = wk + C;                        // [C]
   float* lred = dn + C;                      // [HD_THREADS]
   const int tid = threadIdx.x, b_ = blockIdx.x;
-  for (int i = tid; i < 2 * C * HD_K; i += HD_THREADS) ws[(i / HD_K) * (HD_K + 1) + (i % HD_K)] = w[i];
+  // time splits as in head_fwd_kernel; partial outputs (dW, db, losses) get one row per (clip, split)
+  const int S = gridDim.y, sp = blockIdx.y;
+  const int cps = ((T + HD_FR - 1) / HD_FR + S - 1) / S;
+  const int f_lo = sp * cps * HD_FR, f_hi = min(T, (sp + 1) * cps * HD_FR);
+  const size_t prow = (size_t)b_ * S + sp;
+  head_stage_rows<2 * C>(ws, w, 2 * C, tid);
   float l_s = 0.f, l_w = 0.f, l_cs = 0.f, l_cw = 0.f, l_cs2 = 0.f;
   if (tid < C) {
     const float wv = weak[(size_t)b_ * C + tid];
@@ -125,12 +173,12 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_kernel(
     if (y_weak) {
       const float yv = y_weak[(size_t)b_ * C + tid];
       g += w_weak * bce_grad(wv, yv) * inv_n_weak;
-      l_w = bce_val(wv, yv);
+      if (sp == 0) l_w = bce_val(wv, yv);  // clip-level terms are counted by the first split only
     }
     if (ema_weak) {
       const float d = wv - ema_weak[(size_t)b_ * C + tid];
       g += w_cons_w * 2.f * d * inv_n_weak;
-      l_cw = d * d;
+      if (sp == 0) l_cw = d * d;
     }
     if (g_weak_ext) g += g_weak_ext[(size_t)b_ * C + tid];
     gwk[tid] = g;
@@ -141,12 +189,9 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_kernel(
 #pragma unroll
   for (int c = 0; c < 2 * C; ++c) dwacc[c] = 0.f;
   float dbacc = 0.f;  // thread c < 2C accumulates its bias gradient
-  for (int f0 = 0; f0 < T; f0 += HD_FR) {
+  for (int f0 = f_lo; f0 < f_hi; f0 += HD_FR) {
     __syncthreads();
-    for (int i = tid; i < HD_FR * HD_K; i += HD_THREADS) {
-      const int f = i / HD_K, k = i % HD_K;
-      xs[f * (HD_K + 1) + k] = (f0 + f < T) ? x[((size_t)b_ * T + f0 + f) * HD_K + k] : 0.f;
-    }
+    head_stage_rows<HD_FR>(xs, x + ((size_t)b_ * T + f0) * HD_K, T - f0, tid);
     if (tid < HD_FR) {
       const int f = tid;
       const bool ok = f0 + f < T;
@@ -210,8 +255,8 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_kernel(
       for (int f = 0; f < HD_FR; ++f) dbacc += dl[f * 2 * C + tid];
   }
 #pragma unroll
-  for (int c = 0; c < 2 * C; ++c) dw_part[((size_t)b_ * 2 * C + c) * HD_K + tid] = dwacc[c];
-  if (tid < 2 * C) db_part[(size_t)b_ * 2 * C + tid] = dbacc;
+  for (int c = 0; c < 2 * C; ++c) dw_part[(prow * 2 * C + c) * HD_K + tid] = dwacc[c];
+  if (tid < 2 * C) db_part[prow * 2 * C + tid] = dbacc;
   // loss partials of this clip (plain sums; the host applies weights and 1/N)
   float vals[6] = {l_s, l_w, l_cs, l_cw, l_cs2, 0.f};
   for (int i = 0; i < 6; ++i) {
@@ -221,7 +266,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_kernel(
     if (tid == 0) {
       float s = 0.f;
       for (int j = 0; j < HD_THREADS; ++j) s += lred[j];
-      loss_part[(size_t)b_ * 6 + i] = s;
+      loss_part[prow * 6 + i] = s;
     }
   }
 }
@@ -262,9 +307,20 @@ extern "C" int bsed_binarize_median(const float* strong, float* out, int B, int 
   return BSED_OK;
 }
 
+// time splits per clip: enough workgroups for ~4 per CU, whole 32-frame chunks each
+extern "C" int bsed_head_splits(int B, int T) {
+  const int chunks = (T + HD_FR - 1) / HD_FR;
+  int S = 1;
+  while (S < 8 && (long)B * S < 1024 && S * 2 <= chunks) S *= 2;
+  return S;
+}
+
 extern "C" int bsed_head_fwd(const float* x, const float* w, const float* b, float* strong, float* sof_raw,
-                             float* weak, float* den, int B, int T, int K, int C, int attention, void* stream) {
+                             float* weak, float* den, float* part, int B, int T, int K, int C, int attention,
+                             void* stream) {
   BSED_CHECK_ARG(x && w && b && strong && sof_raw && weak && den, "bsed_head_fwd: null tensor");
+  const int S = bsed_head_splits(B, T);
+  BSED_CHECK_ARG(S == 1 || part, "bsed_head_fwd: %d time splits need the (B,%d,2,C) scratch buffer", S, S);
   BSED_CHECK_ARG(B > 0 && T > 0, "bsed_head_fwd: bad shape");
   BSED_CHECK_ARG(K == HD_K && C == 20, "bsed_head_fwd: built for K=256, nclass=20 (got %d, %d)", K, C);
   const size_t smem = (size_t)(2 * C * (HD_K + 1) + HD_FR * (HD_K + 1) + HD_FR * 2 * C + 2 * C + 2 * HD_FR * C) * 4;
@@ -273,8 +329,11 @@ extern "C" int bsed_head_fwd(const float* x, const float* w, const float* b, flo
     BSED_HIP(hipFuncSetAttribute((const void*)head_fwd_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
-  hipLaunchKernelGGL(head_fwd_kernel<20>, dim3(B), dim3(HD_THREADS), smem, (hipStream_t)stream, x, w, b, strong,
-                     sof_raw, weak, den, T, attention);
+  hipLaunchKernelGGL(head_fwd_kernel<20>, dim3(B, S), dim3(HD_THREADS), smem, (hipStream_t)stream, x, w, b, strong,
+                     sof_raw, weak, den, part, T, attention);
+  if (S > 1)
+    hipLaunchKernelGGL(head_weak_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, weak, den, B,
+                       S, C);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }
@@ -291,7 +350,8 @@ extern "C" int bsed_head_bwd(const BsedHeadBwdDesc* d, void* stream) {
     BSED_HIP(hipFuncSetAttribute((const void*)head_bwd_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
-  hipLaunchKernelGGL(head_bwd_kernel<20>, dim3(d->B), dim3(HD_THREADS), smem, (hipStream_t)stream, d->x, d->w,
+  hipLaunchKernelGGL(head_bwd_kernel<20>, dim3(d->B, bsed_head_splits(d->B, d->T)), dim3(HD_THREADS), smem,
+                     (hipStream_t)stream, d->x, d->w,
                      d->strong, d->sof_raw, d->weak, d->den, d->y_strong, d->y_weak, d->ema_strong, d->ema_weak,
                      d->ema_strong2, d->g_strong_ext, d->g_weak_ext, d->w_strong, d->w_weak, d->w_cons_s, d->w_cons_w,
                      d->w_cons_s2, d->inv_n_strong, d->inv_n_weak, d->dx, d->dw_part, d->db_part, d->loss_part, d->T,

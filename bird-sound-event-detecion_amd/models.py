@@ -656,8 +656,9 @@ class Predictor(_FlatModule):
         dx, dw_part, db_part, loss_part = ops.head_bwd(x.contiguous(), w, strong.contiguous(), sof.contiguous(),
                                                        weak.contiguous(), den.contiguous(), B, T, K, C,
                                                        self.attention, **loss_kw)
-        ops.reduce_partials(dw_part, B, 1, 2 * C, K, 2 * C, K, self.flat_grad, 0, K, 1)
-        ops.colsum(db_part, B, 2 * C, 2 * C, self.flat_grad[2 * C * K:])
+        rows = dw_part.shape[0]                                   # B x time splits (bsed_head_splits)
+        ops.reduce_partials(dw_part, rows, 1, 2 * C, K, 2 * C, K, self.flat_grad, 0, K, 1)
+        ops.colsum(db_part, rows, 2 * C, 2 * C, self.flat_grad[2 * C * K:])
         return dx, loss_part
 
     def forward(self, x, inference=False):

@@ -537,8 +537,10 @@ def head_fwd(x, w, b, B, T, K, C, attention):
     sof = torch.empty((B, T, C), device=dev, dtype=torch.float32)
     weak = torch.empty((B, C), device=dev, dtype=torch.float32)
     den = torch.empty((B, C), device=dev, dtype=torch.float32)
+    S = L.lib().bsed_head_splits(B, T)
+    part = torch.empty((B, S, 2, C), device=dev, dtype=torch.float32) if S > 1 else None
     L.call("bsed_head_fwd", L.ptr(x), _fp(_dp(w)), _fp(_dp(b)), L.ptr(strong), L.ptr(sof), L.ptr(weak), L.ptr(den),
-           _i(B), _i(T), _i(K), _i(C), _i(1 if attention else 0), L.stream())
+           L.ptr(part), _i(B), _i(T), _i(K), _i(C), _i(1 if attention else 0), L.stream())
     return strong, sof, weak, den
 
 
@@ -550,9 +552,10 @@ def head_bwd(x, w, strong, sof, weak, den, B, T, K, C, attention, y_strong=None,
     dev = x.device
     d = HeadBwdDesc()
     dx = torch.empty((B, T, K), device=dev, dtype=torch.float32)
-    dw_part = torch.empty((B, 2 * C, K), device=dev, dtype=torch.float32)
-    db_part = torch.empty((B, 2 * C), device=dev, dtype=torch.float32)
-    loss_part = torch.empty((B, 6), device=dev, dtype=torch.float32)
+    S = L.lib().bsed_head_splits(B, T)                               # rows per clip in the partial outputs
+    dw_part = torch.empty((B * S, 2 * C, K), device=dev, dtype=torch.float32)
+    db_part = torch.empty((B * S, 2 * C), device=dev, dtype=torch.float32)
+    loss_part = torch.empty((B * S, 6), device=dev, dtype=torch.float32)
     d.x = _p(x); d.w = _dp(w); d.strong = _p(strong); d.sof_raw = _p(sof); d.weak = _p(weak); d.den = _p(den)
     d.y_strong = _p(y_strong); d.y_weak = _p(y_weak); d.ema_strong = _p(ema_strong); d.ema_weak = _p(ema_weak)
     d.g_strong_ext = _p(g_strong); d.g_weak_ext = _p(g_weak); d.ema_strong2 = _p(ema_strong2)

@@ -305,8 +305,12 @@ int bsed_gru_bwd3_rows(int B);
  * and the BCE / MSE loss assembly of train_mt (src/main_baseline.py:431-498).
  *   w (2C,K): rows 0..C-1 = dense.weight, rows C..2C-1 = dense_softmax.weight; b (2C) likewise.
  * ---------------------------------------------------------------------------------------------- */
+/* The head kernels split each clip's frames over S = bsed_head_splits(B, T) workgroups.  bsed_head_fwd needs a
+ * (B,S,2,C) scratch buffer `part` when S > 1; bsed_head_bwd writes S rows per clip into its partial outputs
+ * (dw_part (B*S,2C,K), db_part (B*S,2C), loss_part (B*S,6)): sum over the leading dimension as before. */
+int bsed_head_splits(int B, int T);
 int bsed_head_fwd(const float* x, const float* w, const float* b, float* strong, float* sof_raw, float* weak,
-                  float* den, int B, int T, int K, int C, int attention, void* stream);
+                  float* den, float* part, int B, int T, int K, int C, int attention, void* stream);
 
 /* get_predictions post-processing (src/evaluation_measures.py:188-205): out = median_filter(strong > threshold,
  * size=(win,1)) with scipy.ndimage's window origin and 'reflect' boundary; (B,T,C) float 0/1 mask */
