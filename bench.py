@@ -127,10 +127,23 @@ def main():
     dev = torch.device("cuda", dev_index)
     if "RANK" in os.environ:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=dev)
-        else:
-            torch.distributed.init_process_group(backend)
+        # RCCL prints its version banner (NCCL_DEBUG=VERSION on the GPU boxes) to stdout when the communicator is
+        # created: create it here, under a temporary stdout -> stderr redirection, so that stdout carries the ONE JSON
+        # line and nothing else
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                torch.distributed.init_process_group("nccl", device_id=dev)
+            else:
+                torch.distributed.init_process_group(backend)
+            probe = torch.ones(1, device=dev)
+            torch.distributed.all_reduce(probe)
+            torch.cuda.synchronize()
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from bsed_amd import ops
     from bsed_amd.engine import FlatAdam, SEDTrainer
