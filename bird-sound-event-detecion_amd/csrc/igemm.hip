@@ -673,7 +673,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
 #define W3P_UX 13  // float4 of the activation patch per producer thread (256 threads): PP * CC <= 13312 elements
 #define W3P_UD 8   // float4 of the dy tile per producer thread: 128 positions x 64 channels
 
-template <int MAXS>
+// GEO > 0: the tile geometry of one of the network's layer shapes is a compile-time constant: every LDS offset of the
+// MFMA waves' K loop becomes an instruction immediate and the loop is unrolled (20 instead of 640 v_add per tile and no
+// spills: -7 %).  GEO = 0 keeps everything at run time (any other shape).
+struct W3Geo { int CC, lgTW, PW, PP, ntw; };
+__host__ __device__ constexpr W3Geo w3_geo(int g) {
+  return g == 1 ? W3Geo{64, 4, 18, 180, 2}     // 64 -> 128 channels on the 216 x 16 map
+       : g == 2 ? W3Geo{64, 3, 10, 180, 2}     // 128 -> 128, 216 x 8
+       : g == 3 ? W3Geo{32, 4, 18, 180, 2}     // 32 -> 64, 216 x 32
+       : g == 4 ? W3Geo{64, 2, 6, 204, 1}      // 128 -> 128, 216 x 4
+       : g == 5 ? W3Geo{32, 1, 4, 264, 2}      // 128 -> 128, 216 x 2
+                : W3Geo{0, 0, 0, 0, 0};
+}
+#define W3_NGEO 5
+
+template <int MAXS, int GEO>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad3p_kernel(const WgradParams P) {
   constexpr int NTHR = 256, NW = 4, UX = W3P_UX, UD = W3P_UD;
   const BsedWgradDesc& p = P.d;
@@ -804,45 +818,91 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
   }
-  const uint32_t kstep = 2 * (16 >> P.lgTW) * PW * CC;
-  const uint32_t bstep = 2 * 16 * DYW;
   __syncthreads();  // tile 0 is in buffer 0
   int buf = 0;
+  // fragments of slot group g+1 are requested before the MFMAs of group g issue (two groups live at a time)
+  constexpr int SG = 2, NG = (MAXS + SG - 1) / SG;
   for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x, buf ^= 1) {
-    // fragments of slot group g+1 are requested before the MFMAs of group g issue (two groups live at a time)
-    constexpr int SG = 2, NG = (MAXS + SG - 1) / SG;
-    uint32_t ko = 2 * buf * buf_u16, kb = ko;
-#pragma unroll 1
-    for (int kp = 0; kp < IG_TILE_M; kp += 16, ko += kstep, kb += bstep) {
-      w3_bf16x8 ah[2][SG], al[2][SG], bh, bl;
+    if constexpr (GEO > 0) {
+      constexpr W3Geo Gm = w3_geo(GEO);
+      constexpr uint32_t kstep = 2 * (16 >> Gm.lgTW) * Gm.PW * Gm.CC, bstep = 2 * 16 * 32 * Gm.ntw;
+      constexpr uint32_t xloc = 2 * Gm.PP * Gm.CC, dloc = 2 * IG_TILE_M * 32 * Gm.ntw;
+      const uint32_t bo = 2 * buf * buf_u16;
+      uint32_t xab[MAXS][2], xbb[2];
 #pragma unroll
-      for (int g = 0; g <= NG; ++g) {
-        if (g < NG) {
+      for (int s = 0; s < MAXS; ++s) { xab[s][0] = xa[s][0] + bo; xab[s][1] = xa[s][1] + bo; }
+      xbb[0] = xb[0] + bo; xbb[1] = xb[1] + bo;
 #pragma unroll
-          for (int j = 0; j < SG; ++j) {
-            const int sl = g * SG + j;
-            if (sl < MAXS) {
-              ah[g & 1][j] = w3_frag(xa[sl][0] + ko, xa[sl][1] + ko);
-              al[g & 1][j] = w3_frag(xa[sl][0] + ko + xlo, xa[sl][1] + ko + xlo);
-              if (sl == 0) {
-                bh = w3_frag(xb[0] + kb, xb[1] + kb);
-                bl = w3_frag(xb[0] + kb + dlo, xb[1] + kb + dlo);
+      for (int kpi = 0; kpi < IG_TILE_M / 16; ++kpi) {
+        const uint32_t ko = kpi * kstep, kb = kpi * bstep;
+        w3_bf16x8 ah[2][SG], al[2][SG], bh, bl;
+#pragma unroll
+        for (int g = 0; g <= NG; ++g) {
+          if (g < NG) {
+#pragma unroll
+            for (int j = 0; j < SG; ++j) {
+              const int sl = g * SG + j;
+              if (sl < MAXS) {
+                ah[g & 1][j] = w3_frag(xab[sl][0] + ko, xab[sl][1] + ko);
+                al[g & 1][j] = w3_frag(xab[sl][0] + (ko + xloc), xab[sl][1] + (ko + xloc));
+                if (sl == 0) {
+                  bh = w3_frag(xbb[0] + kb, xbb[1] + kb);
+                  bl = w3_frag(xbb[0] + (kb + dloc), xbb[1] + (kb + dloc));
+                }
               }
             }
           }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (g > 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (g > 0) {
 #pragma unroll
-          for (int j = 0; j < SG; ++j) {
-            const int sl = (g - 1) * SG + j;
-            if (sl < MAXS) {
-              acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[(g - 1) & 1][j], bh, acc[sl], 0, 0, 0);
-              acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[(g - 1) & 1][j], bl, acc[sl], 0, 0, 0);
-              acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[(g - 1) & 1][j], bh, acc[sl], 0, 0, 0);
+            for (int j = 0; j < SG; ++j) {
+              const int sl = (g - 1) * SG + j;
+              if (sl < MAXS) {
+                acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[(g - 1) & 1][j], bh, acc[sl], 0, 0, 0);
+                acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[(g - 1) & 1][j], bl, acc[sl], 0, 0, 0);
+                acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[(g - 1) & 1][j], bh, acc[sl], 0, 0, 0);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    } else {
+      const uint32_t kstep = 2 * (16 >> P.lgTW) * PW * CC;
+      const uint32_t bstep = 2 * 16 * DYW;
+      uint32_t ko = 2 * buf * buf_u16, kb = ko;
+#pragma unroll 1
+      for (int kp = 0; kp < IG_TILE_M; kp += 16, ko += kstep, kb += bstep) {
+        w3_bf16x8 ah[2][SG], al[2][SG], bh, bl;
+#pragma unroll
+        for (int g = 0; g <= NG; ++g) {
+          if (g < NG) {
+#pragma unroll
+            for (int j = 0; j < SG; ++j) {
+              const int sl = g * SG + j;
+              if (sl < MAXS) {
+                ah[g & 1][j] = w3_frag(xa[sl][0] + ko, xa[sl][1] + ko);
+                al[g & 1][j] = w3_frag(xa[sl][0] + ko + xlo, xa[sl][1] + ko + xlo);
+                if (sl == 0) {
+                  bh = w3_frag(xb[0] + kb, xb[1] + kb);
+                  bl = w3_frag(xb[0] + kb + dlo, xb[1] + kb + dlo);
+                }
+              }
             }
           }
           __builtin_amdgcn_sched_barrier(0);
+          if (g > 0) {
+#pragma unroll
+            for (int j = 0; j < SG; ++j) {
+              const int sl = (g - 1) * SG + j;
+              if (sl < MAXS) {
+                acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[(g - 1) & 1][j], bh, acc[sl], 0, 0, 0);
+                acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[(g - 1) & 1][j], bl, acc[sl], 0, 0, 0);
+                acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[(g - 1) & 1][j], bh, acc[sl], 0, 0, 0);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
     }
@@ -1196,16 +1256,36 @@ static int launch_wgrad3(const WgradParams& P, dim3 grid, size_t smem, hipStream
   return launch_wgrad3_bs<MAXS, NW, false>(P, grid, smem, s);
 }
 
-template <int MAXS>
-static int launch_wgrad3p(const WgradParams& P, dim3 grid, size_t smem, hipStream_t s) {
+template <int MAXS, int GEO>
+static int launch_wgrad3p_geo(const WgradParams& P, dim3 grid, size_t smem, hipStream_t s) {
   static bool done = false;
   if (!done) {
-    BSED_HIP(hipFuncSetAttribute((const void*)wgrad3p_kernel<MAXS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    BSED_HIP(hipFuncSetAttribute((const void*)wgrad3p_kernel<MAXS, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
-  hipLaunchKernelGGL((wgrad3p_kernel<MAXS>), grid, dim3(512), 2 * smem, s, P);
+  hipLaunchKernelGGL((wgrad3p_kernel<MAXS, GEO>), grid, dim3(512), 2 * smem, s, P);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
+}
+
+// which compile-time geometry (w3_geo) matches this launch, 0 = none
+static int wgrad3p_geo(const WgradParams& P) {
+  for (int g = 1; g <= W3_NGEO; ++g) {
+    const W3Geo G = w3_geo(g);
+    if (P.CC == G.CC && P.lgTW == G.lgTW && P.PW == G.PW && P.PP == G.PP && P.ntw == G.ntw) return g;
+  }
+  return 0;
+}
+
+template <int MAXS>
+static int launch_wgrad3p(const WgradParams& P, dim3 grid, size_t smem, hipStream_t s) {
+  const int g = getenv("BSED_WGRAD3_NOGEO") ? 0 : wgrad3p_geo(P);
+  if (MAXS == 9 && g == 1) return launch_wgrad3p_geo<9, 1>(P, grid, smem, s);
+  if (MAXS == 9 && g == 2) return launch_wgrad3p_geo<9, 2>(P, grid, smem, s);
+  if (MAXS == 5 && g == 3) return launch_wgrad3p_geo<5, 3>(P, grid, smem, s);
+  if (MAXS == 5 && g == 4) return launch_wgrad3p_geo<5, 4>(P, grid, smem, s);
+  if (MAXS == 5 && g == 5) return launch_wgrad3p_geo<5, 5>(P, grid, smem, s);
+  return launch_wgrad3p_geo<MAXS, 0>(P, grid, smem, s);
 }
 
 // the pipelined kernel takes the multi-tap shapes whose two tile buffers fit in LDS and whose per-thread prefetch fits
@@ -1237,7 +1317,11 @@ extern "C" int bsed_wgrad3_variant(const BsedWgradDesc* desc) {
   dim3 gyz;
   if (wgrad_prepare(desc, P, smem, gyz, 1) != BSED_OK) return -1;
   const int v = wgrad_variant(P);
-  if (wgrad3_pipelined(P, smem)) return (v / 16) * 16 + 1;  // NW field 1 = wgrad3p_kernel<MAXS>
+  if (wgrad3_pipelined(P, smem)) {  // NW field 1 = wgrad3p_kernel<MAXS, GEO>, GEO in bits 8..11
+    const int maxs = v / 16, g = getenv("BSED_WGRAD3_NOGEO") ? 0 : wgrad3p_geo(P);
+    const bool built = (maxs == 9 && (g == 1 || g == 2)) || (maxs == 5 && g >= 3 && g <= 5);
+    return maxs * 16 + 1 + ((built ? g : 0) << 8);
+  }
   return v | (((v % 16) % (P.nct * P.ntw) == 0) ? 1 << 12 : 0);  // bit 12 = the BS template argument
 }
 
