@@ -39,7 +39,11 @@ __device__ __forceinline__ int crow3(int r, int lh) { return (r & 3) + 8 * (r >>
 template <int BN, int STATS, int RB, int PV>
 // (waves_per_eu caps the register budget the allocator aims for: without it the prefetch registers were spilled to
 // scratch right after their loads, which serialised the loads again)
-__global__ __launch_bounds__(I3_THREADS) __attribute__((amdgpu_waves_per_eu(1, RB == 2 ? 2 : 3)))
+// (BN = 128, RB = 1: given "1 to 3" the allocator settled at 228 registers = two workgroups per CU although the
+// kernel fits 152 without a spill; with 38 % of a workgroup's life outside its MFMA loop -- in-kernel stamps -- the
+// third resident workgroup is worth 7 %, so there the minimum is pinned to 3 as well)
+__global__ __launch_bounds__(I3_THREADS)
+__attribute__((amdgpu_waves_per_eu(RB == 2 ? 1 : (BN == 128 ? 3 : 1), RB == 2 ? 2 : 3)))
 void igemm3_kernel(const Igemm3Params P) {
   constexpr int NT = BN / 32;
   const BsedIgemmDesc& p = P.d;
