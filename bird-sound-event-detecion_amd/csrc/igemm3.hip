@@ -43,7 +43,7 @@ template <int BN, int STATS, int RB, int PV>
 // kernel fits 152 without a spill; with 38 % of a workgroup's life outside its MFMA loop -- in-kernel stamps -- the
 // third resident workgroup is worth 7 %, so there the minimum is pinned to 3 as well)
 __global__ __launch_bounds__(I3_THREADS)
-__attribute__((amdgpu_waves_per_eu(RB == 2 ? 1 : (BN == 128 ? 3 : 1), RB == 2 ? 2 : 3)))
+__attribute__((amdgpu_waves_per_eu(RB == 2 ? 1 : ((BN == 128 && PV <= 9) ? 3 : 1), RB == 2 ? 2 : 3)))  // (PV = 12 would spill at 3)
 void igemm3_kernel(const Igemm3Params P) {
   constexpr int NT = BN / 32;
   const BsedIgemmDesc& p = P.d;
