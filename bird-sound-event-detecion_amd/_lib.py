@@ -65,6 +65,11 @@ def ptr(t, dtype=None):
         return ctypes.c_void_p(0)
     if not t.is_cuda:
         raise BsedError("expected a GPU tensor")
+    if t.device.index != torch._C._cuda_getDevice():
+        # launches go to the CURRENT device's stream (stream() below): a tensor of another GPU would be dereferenced
+        # by a kernel running on the wrong device
+        raise BsedError(f"tensor lives on cuda:{t.device.index} but the current device is "
+                        f"cuda:{torch._C._cuda_getDevice()}: wrap the call in torch.cuda.device(...)")
     if not t.is_contiguous():
         raise BsedError("expected a contiguous tensor")
     want = torch.float32 if dtype is None else dtype

@@ -39,6 +39,23 @@ void bsed_set_error(const char* fmt, ...);
     }                                                                               \
   } while (0)
 
+// Kernels that need more than 64 KB of dynamic LDS have hipFuncAttributeMaxDynamicSharedMemorySize raised once per
+// (kernel, DEVICE): the attribute is per device, so the guard is a per-kernel atomic bitmask indexed by the current
+// device, not a process-wide flag (a second GPU in the same process, or two host threads, stay correct; setting
+// the attribute twice in a race is harmless).
+#include <atomic>
+struct BsedLdsOnce { std::atomic<uint64_t> mask{0}; };
+static inline hipError_t bsed_max_lds(BsedLdsOnce& once, const void* fn, int bytes = 160 * 1024) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (once.mask.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) once.mask.fetch_or(bit, std::memory_order_release);
+  return e;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bsed_bf16x2 __attribute__((ext_vector_type(2)));

@@ -765,11 +765,8 @@ static int launch_glu_fwd3(const Glu3Params& P, int G, hipStream_t s) {
   constexpr int NT = C / 32, KS = C / 16;
   const size_t smem = (size_t)NT * KS * 2 * 64 * 16 + 2 * C * sizeof(float) +
                       (C <= 64 ? (size_t)4 * 32 * (C + 4) * sizeof(float) : 0);  // + the waves' staged y rows
-  static bool done = false;
-  if (!done) {
-    BSED_HIP(hipFuncSetAttribute((const void*)glu_fwd3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
-  }
+  static BsedLdsOnce once;
+  BSED_HIP(bsed_max_lds(once, (const void*)glu_fwd3_kernel<C>));
   hipLaunchKernelGGL((glu_fwd3_kernel<C>), dim3(G), dim3(G3_THREADS), smem, s, P);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
@@ -784,11 +781,8 @@ static size_t glu_bwd3_smem() {
 template <int C>
 static int launch_glu_bwd3(const Glu3Params& P, int G, hipStream_t s) {
   const size_t smem = glu_bwd3_smem<C>();
-  static bool done = false;
-  if (!done) {
-    BSED_HIP(hipFuncSetAttribute((const void*)glu_bwd3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
-  }
+  static BsedLdsOnce once;
+  BSED_HIP(bsed_max_lds(once, (const void*)glu_bwd3_kernel<C>));
   hipLaunchKernelGGL((glu_bwd3_kernel<C>), dim3(G), dim3(G3_THREADS), smem, s, P);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
@@ -879,11 +873,8 @@ extern "C" int bsed_glu_bwd3n(const float* y, const float* scale, const float* s
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(glu3_pack_frags_kernel, dim3(4 * 8 * 64 / 256), dim3(256), 0, s, w, (bf16x8*)frag_table);
   const size_t smem = bsed_glu_bwd3n_table_bytes() + 2 * 128 * sizeof(float) + (size_t)8 * 32 * (2 * 16 + 8) * 2;
-  static bool done = false;
-  if (!done) {
-    BSED_HIP(hipFuncSetAttribute((const void*)glu_bwd3n_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
-  }
+  static BsedLdsOnce once;
+  BSED_HIP(bsed_max_lds(once, (const void*)glu_bwd3n_kernel));
   hipLaunchKernelGGL(glu_bwd3n_kernel, dim3(G), dim3(G3N_THREADS), smem, s, P, (const bf16x8*)frag_table, dlin);
   BSED_LAUNCH_CHECK();
   return BSED_OK;

@@ -289,11 +289,8 @@ __global__ __launch_bounds__(NW * 64) void glu_bwd_fused_kernel(const GluBwdPara
 template <int C, int NW>
 static int launch_glu_bwd(const GluBwdParams& P, int G, hipStream_t s) {
   const size_t smem = ((size_t)2 * GB_M * (C + 1) + (C <= 32 ? 2 * C * C : 32 * C)) * sizeof(float);
-  static bool done = false;
-  if (!done) {
-    BSED_HIP(hipFuncSetAttribute((const void*)glu_bwd_fused_kernel<C, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
-  }
+  static BsedLdsOnce once;
+  BSED_HIP(bsed_max_lds(once, (const void*)glu_bwd_fused_kernel<C, NW>));
   hipLaunchKernelGGL((glu_bwd_fused_kernel<C, NW>), dim3(G), dim3(NW * 64), smem, s, P);
   BSED_LAUNCH_CHECK();
   return BSED_OK;

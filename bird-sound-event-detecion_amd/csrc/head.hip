@@ -324,11 +324,8 @@ extern "C" int bsed_head_fwd(const float* x, const float* w, const float* b, flo
   BSED_CHECK_ARG(B > 0 && T > 0, "bsed_head_fwd: bad shape");
   BSED_CHECK_ARG(K == HD_K && C == 20, "bsed_head_fwd: built for K=256, nclass=20 (got %d, %d)", K, C);
   const size_t smem = (size_t)(2 * C * (HD_K + 1) + HD_FR * (HD_K + 1) + HD_FR * 2 * C + 2 * C + 2 * HD_FR * C) * 4;
-  static bool done = false;
-  if (!done) {
-    BSED_HIP(hipFuncSetAttribute((const void*)head_fwd_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
-  }
+  static BsedLdsOnce once;
+  BSED_HIP(bsed_max_lds(once, (const void*)head_fwd_kernel<20>));
   hipLaunchKernelGGL(head_fwd_kernel<20>, dim3(B, S), dim3(HD_THREADS), smem, (hipStream_t)stream, x, w, b, strong,
                      sof_raw, weak, den, part, T, attention);
   if (S > 1)
@@ -345,11 +342,8 @@ extern "C" int bsed_head_bwd(const BsedHeadBwdDesc* d, void* stream) {
   BSED_CHECK_ARG(d->B > 0 && d->T > 0 && d->K == HD_K && d->C == 20, "bsed_head_bwd: built for K=256, nclass=20");
   const int C = 20;
   const size_t smem = (size_t)(2 * C * (HD_K + 1) + HD_FR * (HD_K + 1) + HD_FR * 2 * C + 3 * C + HD_THREADS) * 4;
-  static bool done = false;
-  if (!done) {
-    BSED_HIP(hipFuncSetAttribute((const void*)head_bwd_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
-  }
+  static BsedLdsOnce once;
+  BSED_HIP(bsed_max_lds(once, (const void*)head_bwd_kernel<20>));
   hipLaunchKernelGGL(head_bwd_kernel<20>, dim3(d->B, bsed_head_splits(d->B, d->T)), dim3(HD_THREADS), smem,
                      (hipStream_t)stream, d->x, d->w,
                      d->strong, d->sof_raw, d->weak, d->den, d->y_strong, d->y_weak, d->ema_strong, d->ema_weak,

@@ -1016,12 +1016,8 @@ static int launch_igemm_epi(const IgemmParams& P, dim3 grid, size_t smem, hipStr
   switch (P.d.epilogue) {
 #define CASE(E)                                                                                       \
   case E: {                                                                                           \
-    static bool done = false;                                                                         \
-    if (!done) {                                                                                      \
-      BSED_HIP(hipFuncSetAttribute((const void*)igemm_kernel<KC, BN, E>,                              \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));          \
-      done = true;                                                                                    \
-    }                                                                                                 \
+    static BsedLdsOnce once;                                                                         \
+    BSED_HIP(bsed_max_lds(once, (const void*)igemm_kernel<KC, BN, E>));                                                                                                 \
     hipLaunchKernelGGL((igemm_kernel<KC, BN, E>), grid, dim3(IG_THREADS), smem, s, P);                \
     break;                                                                                            \
   }
@@ -1107,11 +1103,8 @@ extern "C" int bsed_igemm(const BsedIgemmDesc* desc, void* stream) {
 
 template <int MAXS, int NW>
 static int launch_wgrad(const WgradParams& P, dim3 grid, size_t smem, hipStream_t s) {
-  static bool done = false;
-  if (!done) {
-    BSED_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<MAXS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
-  }
+  static BsedLdsOnce once;
+  BSED_HIP(bsed_max_lds(once, (const void*)wgrad_kernel<MAXS, NW>));
   hipLaunchKernelGGL((wgrad_kernel<MAXS, NW>), grid, dim3(NW * 64), smem, s, P);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
@@ -1240,11 +1233,8 @@ extern "C" int bsed_wgrad(const BsedWgradDesc* desc, void* stream) {
 
 template <int MAXS, int NW, bool BS>
 static int launch_wgrad3_bs(const WgradParams& P, dim3 grid, size_t smem, hipStream_t s) {
-  static bool done = false;
-  if (!done) {
-    BSED_HIP(hipFuncSetAttribute((const void*)wgrad3_kernel<MAXS, NW, BS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
-  }
+  static BsedLdsOnce once;
+  BSED_HIP(bsed_max_lds(once, (const void*)wgrad3_kernel<MAXS, NW, BS>));
   hipLaunchKernelGGL((wgrad3_kernel<MAXS, NW, BS>), grid, dim3(NW * 64), smem, s, P);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
@@ -1258,11 +1248,8 @@ static int launch_wgrad3(const WgradParams& P, dim3 grid, size_t smem, hipStream
 
 template <int MAXS, int GEO>
 static int launch_wgrad3p_geo(const WgradParams& P, dim3 grid, size_t smem, hipStream_t s) {
-  static bool done = false;
-  if (!done) {
-    BSED_HIP(hipFuncSetAttribute((const void*)wgrad3p_kernel<MAXS, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
-  }
+  static BsedLdsOnce once;
+  BSED_HIP(bsed_max_lds(once, (const void*)wgrad3p_kernel<MAXS, GEO>));
   hipLaunchKernelGGL((wgrad3p_kernel<MAXS, GEO>), grid, dim3(512), 2 * smem, s, P);
   BSED_LAUNCH_CHECK();
   return BSED_OK;

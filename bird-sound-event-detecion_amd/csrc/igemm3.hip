@@ -461,11 +461,8 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
 
 template <int BN, int STATS, int RB, int PV>
 static int launch_i3pv(const Igemm3Params& P, dim3 grid, size_t smem, hipStream_t s) {
-  static bool done = false;
-  if (!done) {
-    BSED_HIP(hipFuncSetAttribute((const void*)igemm3_kernel<BN, STATS, RB, PV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
-  }
+  static BsedLdsOnce once;
+  BSED_HIP(bsed_max_lds(once, (const void*)igemm3_kernel<BN, STATS, RB, PV>));
   hipLaunchKernelGGL((igemm3_kernel<BN, STATS, RB, PV>), grid, dim3(I3_THREADS), smem, s, P);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
@@ -585,12 +582,8 @@ extern "C" int bsed_igemm3s(const BsedIgemmDesc* desc, int G, void* stream) {
   const bool st = d.epilogue == BSED_EPI_STATS;
 #define I3S_LAUNCH1(S, T, K, V)                                                                                       \
   do {                                                                                                                \
-    static bool done = false;                                                                                         \
-    if (!done) {                                                                                                      \
-      BSED_HIP(hipFuncSetAttribute((const void*)igemm3s_kernel<S, T, K, V>,                                           \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                          \
-      done = true;                                                                                                    \
-    }                                                                                                                 \
+    static BsedLdsOnce once;                                                                                         \
+    BSED_HIP(bsed_max_lds(once, (const void*)igemm3s_kernel<S, T, K, V>));                                                                                                                 \
     hipLaunchKernelGGL((igemm3s_kernel<S, T, K, V>), grid, dim3(I3_THREADS), bytes, s, P);                            \
   } while (0)
 #define I3S_LAUNCH(T, K)                                                                                              \

@@ -333,11 +333,8 @@ extern "C" int bsed_mel_linear(const void* plan, const float* wav, int B, int n_
   BSED_CHECK_ARG(smem <= 160 * 1024, "bsed_mel_linear: hop %d needs %zu B of LDS", p->cfg.hop, smem);
   BSED_HIP(hipMemsetAsync(clip_max, 0, (size_t)B * sizeof(float), s));
   BSED_HIP(hipMemsetAsync(bin_sumsq, 0, (size_t)B * p->cfg.n_mels * sizeof(float), s));
-  static bool attr_set = false;
-  if (!attr_set) {
-    BSED_HIP(hipFuncSetAttribute((const void*)stft_mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static BsedLdsOnce once;
+  BSED_HIP(bsed_max_lds(once, (const void*)stft_mel_kernel));
   dim3 grid(ceil_div(T, FPB), B);
   hipLaunchKernelGGL(stft_mel_kernel, grid, dim3(MEL_THREADS), smem, s, wav, n_samples, p->cfg.hop, T,
                      p->cfg.n_mels, p->d_window, p->d_w1024, p->d_w2048, p->d_mel_start, p->d_mel_count,

@@ -25,6 +25,11 @@ def _i(v):
     return ctypes.c_int(v)
 
 
+def grl_coeff(iter_num, alpha=1.0, lo=0.0, hi=1.0, max_iters=1000.0):
+    """WarmStartGradientReverseLayer coefficient at call ``iter_num`` (reference src/DA/grl.py:62-67)"""
+    return float(2.0 * (hi - lo) / (1.0 + np.exp(-alpha * iter_num / max_iters)) - (hi - lo) + lo)
+
+
 def _im2col(act, scale, shift, N, Hi, Wi, C, CP):
     Ho, Wo = (Hi - 3) // 2 + 1, (Wi - 3) // 2 + 1
     K = 16 if C == 1 else 9 * CP
@@ -234,8 +239,7 @@ class ConditionalDomainAdversarialLoss(nn.Module):
         self._ctx = None
 
     def grl_coeff(self):
-        return float(2.0 * (self.hi - self.lo) / (1.0 + np.exp(-self.alpha * self.iter_num / self.max_iters))
-                     - (self.hi - self.lo) + self.lo)
+        return grl_coeff(self.iter_num, self.alpha, self.lo, self.hi, self.max_iters)
 
     def forward(self, g_s, f_s, g_t, f_t):
         coeff = self.grl_coeff()

@@ -17,6 +17,7 @@ Only the hot-path configuration is built: GLU activation, 3x3/stride-1/pad-1 con
 and 2 layers, 20 classes; anything else raises NotImplementedError (no silent fallback).
 """
 import math
+import re
 from collections import OrderedDict
 
 import numpy as np
@@ -114,6 +115,8 @@ def _check_cfg(cond, what):
 
 
 class CRNN(_FlatModule):
+    _RUNS_RNN = True  # False: the GRU only owns state-dict entries (CRNN_pred)
+
     def __init__(self, n_in_channel, nclass, attention=False, activation="Relu", dropout=0, train_cnn=True,
                  rnn_type="BGRU", n_RNN_cell=64, n_layers_RNN=1, dropout_recurrent=0, cnn_integration=False,
                  learned_post=False, kernel_size=(3, 3, 3), padding=(1, 1, 1), stride=(1, 1, 1),
@@ -122,8 +125,10 @@ class CRNN(_FlatModule):
         L._require_gpu()
         _check_cfg(n_in_channel == 1 and not cnn_integration, "n_in_channel=1")
         _check_cfg(activation.lower() == "glu", 'activation="glu"')
-        _check_cfg(rnn_type == "BGRU" and n_RNN_cell == 128 and n_layers_RNN == 2 and dropout_recurrent == 0,
-                   "BGRU, 128 cells, 2 layers, no recurrent dropout")
+        _check_cfg(rnn_type == "BGRU" and dropout_recurrent == 0, "BGRU without recurrent dropout")
+        if self._RUNS_RNN:
+            _check_cfg(n_RNN_cell == 128 and n_layers_RNN == 2, "128 GRU cells, 2 layers")
+        self.nclass, self.n_layers = nclass, n_layers_RNN
         _check_cfg(all(k == 3 for k in kernel_size) and all(p == 1 for p in padding) and all(s == 1 for s in stride),
                    "3x3 / stride 1 / pad 1 convolutions")
         nb_filters = list(nb_filters)
@@ -154,7 +159,7 @@ class CRNN(_FlatModule):
             bspecs += [(f"cnn.batchnorm{i}.running_mean", (co,)), (f"cnn.batchnorm{i}.running_var", (co,))]
             cin = co
         H = n_RNN_cell
-        for l in range(2):
+        for l in range(n_layers_RNN):
             nin = nb_filters[-1] if l == 0 else 2 * H
             # forward and reverse tensors are adjacent so (768, nin) / (2,384,128) views cover both directions
             pspecs += [(f"rnn.rnn.weight_ih_l{l}", (3 * H, nin)), (f"rnn.rnn.weight_ih_l{l}_reverse", (3 * H, nin)),
@@ -163,6 +168,7 @@ class CRNN(_FlatModule):
                        (f"rnn.rnn.bias_hh_l{l}", (3 * H,)), (f"rnn.rnn.bias_hh_l{l}_reverse", (3 * H,))]
         ep, eb, extra_bn = self._extra_specs()
         self._build(pspecs + ep, bspecs + eb, device)
+        self._init_order = self._init_roles()
         self.nbt = torch.zeros(len(nb_filters) + len(extra_bn), device=device, dtype=torch.int64)
         for i in range(len(nb_filters)):
             self.P(f"cnn.batchnorm{i}").register_buffer("num_batches_tracked", self.nbt[i])
@@ -173,6 +179,24 @@ class CRNN(_FlatModule):
     def _extra_specs(self):
         """(parameter specs, buffer specs, names of extra BatchNorm modules) of a subclass"""
         return [], [], []
+
+    def _gru_roles(self, prefix):
+        """GRU tensors in nn.GRU.parameters() order (the order the reference's weights_init walks them in)"""
+        out = []
+        for l in range(self.n_layers):
+            for sfx in ("", "_reverse"):
+                out += [(f"{prefix}.rnn.weight_ih_l{l}{sfx}", "gru"), (f"{prefix}.rnn.weight_hh_l{l}{sfx}", "gru"),
+                        (f"{prefix}.rnn.bias_ih_l{l}{sfx}", "gru"), (f"{prefix}.rnn.bias_hh_l{l}{sfx}", "gru")]
+        return out
+
+    def _init_roles(self):
+        """[(module prefix or GRU tensor, role)] in the order ``reference_model.apply(weights_init)`` visits the
+        modules that own parameters (src/models/CNN.py:43-69, src/models/CRNN_GRL.py:144-173): what a tensor IS
+        (conv / bn / linear / gru) is recorded here, not guessed from its name."""
+        order = []
+        for i in range(len(self.nb_filters)):
+            order += [(f"cnn.conv{i}", "conv"), (f"cnn.batchnorm{i}", "bn"), (f"cnn.glu{i}.linear", "linear")]
+        return order + self._gru_roles("rnn")
 
     # ------------------------------------------------------------------ init / state
     @torch.no_grad()
@@ -203,7 +227,7 @@ class CRNN(_FlatModule):
         # reference checkpoints carry "cnn.conv0.weight"; its loaders rewrite to "cnn.cnn." (save_features.py:48-52)
         sd = OrderedDict((k.replace("cnn.cnn.", "cnn.", 1) if k.startswith("cnn.cnn.") else k, v)
                          for k, v in state_dict.items())
-        own = self.state_dict()
+        own = nn.Module.state_dict(self)
         missing = [k for k in own if k not in sd]
         unexpected = [k for k in sd if k not in own]
         if strict and (missing or unexpected):
@@ -510,6 +534,25 @@ class CRNN_fpn(CRNN):
         bs = [("cnn.bn_fcn.running_mean", (128,)), ("cnn.bn_fcn.running_var", (128,))]
         return ps, bs, ["cnn.bn_fcn"]
 
+    def _init_roles(self):
+        # reference module order: src/models/CNN_FPN.py:66-77 (cnn, cnn_fcn, glu, bn_fcn, conv1x1) then
+        # src/models/CRNN_GRL.py:304-336 (rnn, rnn_2, rnn_4, conv1x1_2, conv1x1_4)
+        order = []
+        for i in range(len(self.nb_filters)):
+            order += [(f"cnn.conv{i}", "conv"), (f"cnn.batchnorm{i}", "bn"), (f"cnn.glu{i}.linear", "linear")]
+        order += [("cnn.cnn_fcn", "conv"), ("cnn.glu.linear", "linear"), ("cnn.bn_fcn", "bn"), ("cnn.conv1x1", "conv")]
+        for pfx in ("rnn", "rnn_2", "rnn_4"):
+            order += self._gru_roles(pfx)
+        return order + [("conv1x1_2", "conv"), ("conv1x1_4", "conv")]
+
+    _BASE_KEY = re.compile(r"^cnn\.(conv\d+|batchnorm\d+|glu\d+)\.")
+
+    def state_dict(self, *args, **kwargs):
+        """the reference's CNN_FPN keeps its seven base blocks in a Sequential named ``cnn`` and (unlike CNN) does not
+        strip that level: its keys are ``cnn.cnn.conv0.weight`` ... next to ``cnn.cnn_fcn.weight`` (CNN_FPN.py:41-77)"""
+        sd = super().state_dict(*args, **kwargs)
+        return OrderedDict((("cnn." + k if self._BASE_KEY.match(k) else k), v) for k, v in sd.items())
+
     # 1x1 convolution over channels of a (B,T,512) sequence == GEMM with the (256,512) weight
     def _fuse(self, cat, name, B, T):
         w, b = self.P(name + ".weight"), self.P(name + ".bias")
@@ -600,6 +643,60 @@ class CRNN_fpn(CRNN):
         self._cnn_backward(ctx, d_a.view(B, T, 1, C))
 
 
+class CRNN_pred(CRNN):
+    """Drop-in for the reference's CNN-only tagger ``CRNN_pred`` (src/models/CRNN_GRL.py:206-290; BASELINE configs[1]):
+    the CNN stack, then -- with the GRU commented out in the reference's forward -- ``strong = sigmoid(features)``,
+    ``sof = clamp(softmax_class(dense_softmax(features)), 1e-7, 1)``, ``weak = sum_t strong*sof / sum_t sof``.
+    ``forward(x, inference=False) -> (strong (B,T',C), weak (B,C))``.  The reference's shapes only agree for
+    ``nclass == nb_filters[-1] == 2 * n_RNN_cell`` (the sigmoid acts on the 128 feature channels themselves), which is
+    what is built.  ``rnn.*`` exists because the reference module owns those state-dict entries; no kernel reads it.
+    Forward only (the reference never trains this module: no script instantiates it)."""
+    _RUNS_RNN = False
+
+    def __init__(self, n_in_channel, nclass, attention=False, activation="Relu", dropout=0, train_cnn=True,
+                 rnn_type="BGRU", n_RNN_cell=64, n_layers_RNN=1, dropout_recurrent=0, cnn_integration=False,
+                 learned_post=False, **cnn_kwargs):
+        nb = list(cnn_kwargs.get("nb_filters", (64, 64, 64)))
+        _check_cfg(nclass == nb[-1] == 2 * n_RNN_cell == 128, "CRNN_pred: nclass == nb_filters[-1] == 2*n_RNN_cell == 128")
+        super().__init__(n_in_channel, nclass, attention, activation, dropout, train_cnn, rnn_type, n_RNN_cell,
+                         n_layers_RNN, dropout_recurrent, cnn_integration, learned_post, **cnn_kwargs)
+
+    def _extra_specs(self):
+        C = self.nclass
+        return [("dense_softmax.weight", (C, C)), ("dense_softmax.bias", (C,))], [], []
+
+    def _init_roles(self):
+        # reference module order (CRNN_GRL.py:211-236): dense_softmax is created before the CNN
+        return [("dense_softmax", "linear")] + super()._init_roles()
+
+    def run_forward(self, x, save=False):
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise L.BsedError(f"CRNN_pred expects (B,1,T,F), got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        B = x.shape[0]
+        a, T = self._cnn_forward(x, None)
+        C = self.nclass
+        feats = a.view(B, T, C)
+        w, b = self.P("dense_softmax.weight"), self.P("dense_softmax.bias")
+        if self.conv_mode == "bf16x3":
+            w3 = ops.pack_weight3(w, 1, C, C, 0, 1, C)
+            logits, _ = ops.igemm3(feats, w3, C, 1, B * T, 1, C, ((0, 0),), bias=b)
+        else:
+            wpk = ops.pack_weight(w, 1, C, C, 0, 1, C)
+            logits, _ = ops.igemm(feats, wpk, C, 1, B * T, 1, C, bias=b)
+        return ops.tag_head_fwd(feats, logits.view(B, T, C))
+
+    def run_backward(self, ctx, d):
+        raise NotImplementedError("CRNN_pred is forward only (BASELINE configs[1]: CNN-only tagging forward)")
+
+    def forward(self, x, inference=False):
+        strong, weak = self.run_forward(x)
+        if inference:
+            # reference CRNN_GRL.py:282-287 (hard-codes 313 frames and .cuda() there; any T here)
+            strong = strong * (weak > 0.5).float().unsqueeze(1)
+        return strong, weak
+
+
 class _CRNNFunction(torch.autograd.Function):
     """autograd bridge so reference-style drivers (loss.backward(); optimizer.step()) keep working."""
 
@@ -627,6 +724,7 @@ class Predictor(_FlatModule):
         pspecs = [("dense.weight", (nclass, self.K)), ("dense_softmax.weight", (nclass, self.K)),
                   ("dense.bias", (nclass,)), ("dense_softmax.bias", (nclass,))]
         self._build(pspecs, [], device)
+        self._init_order = [("dense", "linear")] + ([("dense_softmax", "linear")] if attention else [])
         if not attention:
             # the reference has no dense_softmax without attention: keep the tensors out of the state dict
             del self.dense_softmax
@@ -693,32 +791,32 @@ class _PredictorFunction(torch.autograd.Function):
 
 
 def weights_init(m):
-    """Reference ``weights_init`` (src/utilities/utils.py:40-63) applied to a bsed_amd CRNN / Predictor:
-    xavier-uniform(gain sqrt2) convs with zero bias, BN ~ N(1, 0.02) / 0, orthogonal GRU matrices,
-    N(0, 0.01) Linear weights with zero bias (this includes the GLU's Linear)."""
-    if not isinstance(m, (CRNN, Predictor)):
+    """Reference ``weights_init`` (src/utilities/utils.py:40-63) for a bsed_amd module: xavier-uniform(gain sqrt 2)
+    convolutions with zero bias, BatchNorm ~ N(1, 0.02) / 0, orthogonal GRU matrices (biases untouched), N(0, 0.01)
+    Linear weights with zero bias (this includes the GLU's Linear).  The role of every tensor comes from the module's
+    ``_init_order`` table (what the tensor IS), and the draws are made on the CPU generator in the order
+    ``reference_model.apply(weights_init)`` makes them, so the same ``torch.manual_seed`` gives the reference's weights."""
+    order = getattr(m, "_init_order", None)
+    if order is None:
         return
     with torch.no_grad():
-        for name, p in m.named_parameters():
-            if ".conv" in name:
-                if name.endswith("weight"):
-                    t = torch.empty(p.shape)
-                    nn.init.xavier_uniform_(t, gain=np.sqrt(2))
-                    p.copy_(t)
-                else:
-                    p.zero_()
-            elif "batchnorm" in name:
-                if name.endswith("weight"):
-                    p.copy_(torch.empty(p.shape).normal_(1.0, 0.02))
-                else:
-                    p.zero_()
-            elif name.startswith("rnn"):
+        for name, role in order:
+            if role == "gru":
+                p = m.P(name)
                 if p.dim() > 1:
                     t = torch.empty(p.shape)
                     nn.init.orthogonal_(t)
                     p.copy_(t)
-            else:  # Linear: GLU linear, dense, dense_softmax
-                if name.endswith("weight"):
-                    p.copy_(torch.empty(p.shape).normal_(0, 0.01))
-                else:
-                    p.zero_()
+                continue
+            w, b = m.P(name + ".weight"), m.P(name + ".bias")
+            if role == "conv":
+                t = torch.empty(w.shape)
+                nn.init.xavier_uniform_(t, gain=np.sqrt(2))
+            elif role == "bn":
+                t = torch.empty(w.shape).normal_(1.0, 0.02)
+            elif role == "linear":
+                t = torch.empty(w.shape).normal_(0, 0.01)
+            else:
+                raise L.BsedError(f"weights_init: unknown role {role!r} for {name}")
+            w.copy_(t)
+            b.zero_()

@@ -568,6 +568,18 @@ def head_bwd(x, w, strong, sof, weak, den, B, T, K, C, attention, y_strong=None,
     return dx, dw_part, db_part, loss_part
 
 
+def tag_head_fwd(x, logits):
+    """CNN-only tagging head (csrc/tag.hip): x, logits (B,T,128) -> (strong (B,T,128), weak (B,128))"""
+    B, T, C = x.shape
+    S = L.lib().bsed_tag_splits(B, T)
+    strong = torch.empty_like(x)
+    weak = torch.empty((B, C), device=x.device, dtype=torch.float32)
+    part = torch.empty((B, S, 2, C), device=x.device, dtype=torch.float32)
+    L.call("bsed_tag_head_fwd", L.ptr(x), L.ptr(logits), L.ptr(strong), L.ptr(weak), L.ptr(part), _i(B), _i(T), _i(C),
+           L.stream())
+    return strong, weak
+
+
 def adam_step(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
     L.call("bsed_adam_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), ctypes.c_long(p.numel()), ctypes.c_float(lr),
            ctypes.c_float(betas[0]), ctypes.c_float(betas[1]), ctypes.c_float(eps), ctypes.c_float(weight_decay),

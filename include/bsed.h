@@ -312,6 +312,13 @@ int bsed_head_splits(int B, int T);
 int bsed_head_fwd(const float* x, const float* w, const float* b, float* strong, float* sof_raw, float* weak,
                   float* den, float* part, int B, int T, int K, int C, int attention, void* stream);
 
+/* CNN-only tagging head (csrc/tag.hip); replaces the tail of CRNN_pred.forward (src/models/CRNN_GRL.py:252-290):
+ * strong = sigmoid(x), sof = clamp(softmax_class(logits), 1e-7, 1), weak = sum_t strong*sof / sum_t sof.
+ *   x, logits, strong (B,T,C); weak (B,C); part: (B, bsed_tag_splits(B,T), 2, C) scratch.  C = 128. */
+int bsed_tag_splits(int B, int T);
+int bsed_tag_head_fwd(const float* x, const float* logits, float* strong, float* weak, float* part, int B, int T, int C,
+                      void* stream);
+
 /* get_predictions post-processing (src/evaluation_measures.py:188-205): out = median_filter(strong > threshold,
  * size=(win,1)) with scipy.ndimage's window origin and 'reflect' boundary; (B,T,C) float 0/1 mask */
 int bsed_binarize_median(const float* strong, float* out, int B, int T, int C, float threshold, int win,

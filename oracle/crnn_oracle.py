@@ -9,6 +9,7 @@ can exchange weights; pinned by ``tests/golden/crnn_*.npz`` (oracle/gen_golden.p
   * BidirectionalGRU     <- src/models/RNN.py:7-16
   * CRNN                 <- src/models/CRNN_GRL.py:142-204
   * Predictor            <- src/models/CRNN_GRL.py:430-460
+  * CRNN_pred            <- src/models/CRNN_GRL.py:206-290 (CNN-only tagger, BASELINE configs[1])
   * Clip_Discriminator   <- src/models/CRNN_GRL.py:16-53
   * weights_init         <- src/utilities/utils.py:40-63
   * update_ema_variables <- src/main_baseline.py:91-105
@@ -106,6 +107,29 @@ class CRNN(nn.Module):
         x = x.squeeze(-1).permute(0, 2, 1)
         x = self.dropout(self.rnn(x))
         return x, x
+
+
+class CRNN_pred(nn.Module):
+    """reference src/models/CRNN_GRL.py:206-290: CNN stack, sigmoid on the features themselves, class-softmax attention
+    pooling through dense_softmax; the GRU is constructed (state-dict entries) but its call is commented out there."""
+
+    def __init__(self, n_in_channel, nclass, attention=False, activation="Relu", dropout=0, train_cnn=True,
+                 rnn_type="BGRU", n_RNN_cell=64, n_layers_RNN=1, dropout_recurrent=0, cnn_integration=False,
+                 learned_post=False, **kwargs):
+        super().__init__()
+        self.dense_softmax = nn.Linear(n_RNN_cell * 2, nclass)
+        self.cnn = CNN(n_in_channel, activation, dropout, **kwargs)
+        self.rnn = BidirectionalGRU(self.cnn.nb_filters[-1], n_RNN_cell, dropout=dropout_recurrent,
+                                    num_layers=n_layers_RNN)
+
+    def forward(self, x, inference=False):
+        x = self.cnn(x).squeeze(-1).permute(0, 2, 1)
+        strong = torch.sigmoid(x)
+        sof = torch.clamp(torch.softmax(self.dense_softmax(x), dim=-1), min=1e-7, max=1)
+        weak = (strong * sof).sum(1) / sof.sum(1)
+        if inference:
+            strong = strong * (weak > 0.5).float().unsqueeze(1)
+        return strong, weak
 
 
 class CNN_FPN(nn.Module):

@@ -39,7 +39,10 @@ def _stub(name, **attrs):
 
 # third-party modules the reference imports at top level but that are absent here
 _stub("soundfile")
-_stub("librosa")
+from oracle import mel_oracle as _mo  # noqa: E402
+# librosa is absent: the reference's Transforms.py only calls librosa.amplitude_to_db, which is handed the
+# restatement -- everything else that runs below (noise, pad/trunc, tensor conversion, pipeline order) is the reference's
+_stub("librosa", amplitude_to_db=_mo.amplitude_to_db)
 _stub("dcase_util")
 _stub("dcase_util.data", DecisionEncoder=object)
 # data.config allocates 2.6 GB at import: hand the constants in instead
@@ -321,9 +324,93 @@ def fpn_case():
     print("wrote crnn_fpn.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in list(g.items())[:6]})
 
 
+def transforms_case():
+    """AugmentGaussianNoise.gaussian_noise / pad_trunc_seq / PadOrTrunc / ToTensor and the get_transforms pipeline
+    of the reference (src/data/Transforms.py:89-139,155-227,304-322), run on seeded linear-mel inputs.  Only
+    librosa.amplitude_to_db inside ApplyLog is the restatement's (librosa is not installed)."""
+    from data import Transforms as TR
+    rng = np.random.default_rng(404)
+    T, F = 37, 128
+    x = (np.abs(rng.standard_normal((T, F))) * np.exp(rng.uniform(-6, 2, (1, F)))).astype(np.float32)
+    g = {"x": x}
+    np.random.seed(2023)
+    g["noisy_snr30"] = TR.AugmentGaussianNoise.gaussian_noise(x, 30)
+    np.random.seed(7)
+    x3 = np.stack([x, 0.5 * x])                         # the 3-D branch: std from features[0] only
+    g["noisy3d_snr20"] = TR.AugmentGaussianNoise.gaussian_noise(x3, 20)
+    g["pad50"] = TR.pad_trunc_seq(x, 50)
+    g["trunc20"] = TR.pad_trunc_seq(x, 20)
+    g["same37"] = TR.pad_trunc_seq(x, 37)
+    g["pad3d_40"] = TR.pad_trunc_seq(x3, 40)
+    lab = (rng.random((9, 20)) < 0.3).astype(np.float64)
+    for tag, frames in (("pad", 50), ("trunc", 20)):
+        np.random.seed(99)
+        tf = TR.get_transforms(frames, None, 0, noise_dict_params={"mean": 0., "snr": 30})
+        (clean, noisy), y = tf((x, lab))
+        assert clean.dtype == torch.float32 and noisy.dtype == torch.float32 and y.dtype == torch.float32
+        g[f"pipe_{tag}_clean"], g[f"pipe_{tag}_noisy"], g[f"pipe_{tag}_label"] = clean.numpy(), noisy.numpy(), y.numpy()
+    np.savez_compressed(os.path.join(OUT, "transforms.npz"), **g)
+    print("wrote transforms.npz", {k: v.shape for k, v in g.items()})
+
+
+def fpn_init_case():
+    """per-tensor statistics of the reference's CRNN_fpn after .apply(weights_init) (utilities/utils.py:40-63)"""
+    from models.CRNN_GRL import CRNN_fpn as RefFPN
+    torch.manual_seed(2023)
+    m = RefFPN(**CRNN_KWARGS)
+    m.apply(weights_init)
+    stats = {}
+    for k, v in m.state_dict().items():
+        v = v.double()
+        stats[k] = [float(v.mean()), float(v.std()) if v.numel() > 1 else 0.0, float(v.abs().max()),
+                    float(v.abs().sum())]
+    json.dump(stats, open(os.path.join(OUT, "weights_init_fpn.json"), "w"), indent=0)
+    print("wrote weights_init_fpn.json", len(stats))
+
+
+def cnn_pred_case():
+    """BASELINE configs[1] (CNN-only tagging forward): the reference's CRNN_pred (models/CRNN_GRL.py:206-290) =
+    CNN stack -> sigmoid on the 128 channel features, class-softmax attention pooling with dense_softmax; its GRU
+    exists but forward never calls it.  Shapes only agree for nclass == nb_filters[-1] == 2*n_RNN_cell."""
+    from models.CRNN_GRL import CRNN_pred
+    kw = dict(CRNN_KWARGS)
+    kw.update(nclass=128, n_RNN_cell=64)
+    g = {}
+    for tag, B, T, seed in (("small", 2, 64, 51), ("R", 2, 1255, 52)):
+        x = seeded.db_like_input(seed + 10, B, T)
+        kw["dropout"] = 0.5
+        m = CRNN_pred(**kw)
+        vals = seeded.load_seeded(m, seed)
+        g[f"{tag}_meta"] = np.array([B, T, seed], dtype=np.int64)
+        g[f"{tag}_weight_checksum"] = np.array([seeded.checksum(vals)])
+        g["state_names"] = np.array(list(m.state_dict().keys()))
+        g["state_shapes"] = np.array([str(tuple(v.shape)) for v in m.state_dict().values()])
+        m.eval()
+        with torch.no_grad():
+            strong, weak = m(t(x))
+        g[f"{tag}_eval_strong"], g[f"{tag}_eval_weak"] = strong.numpy(), weak.numpy()
+        kw["dropout"] = 0.0
+        m = CRNN_pred(**kw)
+        seeded.load_seeded(m, seed)
+        m.train()
+        with torch.no_grad():
+            strong, weak = m(t(x))
+        g[f"{tag}_train_strong"], g[f"{tag}_train_weak"] = strong.numpy(), weak.numpy()
+        sd = m.state_dict()
+        g[f"{tag}_after_rm6"] = sd["cnn.batchnorm6.running_mean"].numpy().copy()
+        g[f"{tag}_after_rv6"] = sd["cnn.batchnorm6.running_var"].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "cnn_pred.npz"), **g)
+    print("wrote cnn_pred.npz", {k: getattr(v, "shape", None) for k, v in g.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    only = sys.argv[1:]
+    if only:                       # python oracle/gen_golden.py transforms_case fpn_init_case ...
+        for name in only:
+            globals()[name]()
+        sys.exit(0)
     labels_case()
     schedule_case()
     init_case()
@@ -331,3 +418,6 @@ if __name__ == "__main__":
     crnn_case("small", B=2, T=64, seed=11, adam_steps=3, mt=True)
     crnn_case("R", B=2, T=1255, seed=23, adam_steps=1, mt=False)
     fpn_case()
+    transforms_case()
+    fpn_init_case()
+    cnn_pred_case()

@@ -1,0 +1,52 @@
+"""The PRODUCT ``weights_init`` (bsed_amd.models) against per-tensor statistics of the reference's own
+``model.apply(weights_init)`` (src/utilities/utils.py:40-63) for CRNN + Predictor (tests/golden/weights_init.json) and
+CRNN_fpn (tests/golden/weights_init_fpn.json).  The product draws on the CPU generator in the reference's module
+order, so with the same ``torch.manual_seed`` the tensors are the reference's (LAPACK last bits aside for the
+orthogonal GRU matrices): mean and sum |.| of every tensor are compared, not just distribution shapes."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(sd, ref):
+    for k, (mean, std, amax, asum) in ref.items():
+        if k.startswith("_"):
+            continue
+        v = sd[k].double().cpu()
+        assert abs(float(v.mean()) - mean) < 1e-5 + 1e-4 * abs(mean), (k, float(v.mean()), mean)
+        assert abs(float(v.abs().sum()) - asum) < 1e-3 + 1e-4 * asum, (k, float(v.abs().sum()), asum)
+        assert abs(float(v.abs().max()) - amax) < 1e-5 + 1e-4 * amax, k
+
+
+def test_product_weights_init_matches_reference_crnn(golden_dir):
+    from oracle.crnn_oracle import CRNN_KWARGS, PREDICTOR_KWARGS
+    from bsed_amd.models import CRNN, Predictor, weights_init
+    ref = json.load(open(os.path.join(golden_dir, "weights_init.json")))
+    crnn, pred = CRNN(**CRNN_KWARGS), Predictor(**PREDICTOR_KWARGS)
+    torch.manual_seed(2023)
+    crnn.apply(weights_init)          # the reference's call form: apply() visits every sub-module, only the
+    pred.apply(weights_init)          # flat-arena module itself carries an _init_order
+    sd = {"crnn." + k: v for k, v in crnn.state_dict().items()}
+    sd.update({"pred." + k: v for k, v in pred.state_dict().items()})
+    assert sorted(sd.keys()) == sorted(k for k in ref if not k.startswith("_"))
+    _check(sd, ref)
+    w = crnn.state_dict()["rnn.rnn.weight_hh_l1_reverse"].double().cpu()
+    assert float((w.T @ w - torch.eye(128, dtype=torch.double)).abs().max()) < 1e-5
+
+
+def test_product_weights_init_matches_reference_crnn_fpn(golden_dir):
+    from oracle.crnn_oracle import CRNN_KWARGS
+    from bsed_amd.models import CRNN_fpn, weights_init
+    ref = json.load(open(os.path.join(golden_dir, "weights_init_fpn.json")))
+    m = CRNN_fpn(**CRNN_KWARGS)
+    torch.manual_seed(2023)
+    weights_init(m)
+    sd = m.state_dict()
+    assert sorted(sd.keys()) == sorted(ref.keys())
+    _check(sd, ref)
+    # the pyramid level's BatchNorm scale must start near 1 (round 1 initialised it like a Linear: ~N(0, 0.01))
+    assert abs(float(sd["cnn.bn_fcn.weight"].mean()) - 1.0) < 0.02

@@ -19,19 +19,29 @@ def fe():
     return MelFrontEnd()
 
 
-def _clips(n, seconds):
-    return np.stack([mo.synth_clip(i, seconds=seconds)[0] for i in range(n)])
+@pytest.fixture(scope="module")
+def fe_m():
+    """the BASELINE measurement configuration (bench.py): 22.05 kHz, fmax clamped to 11 025 Hz"""
+    from bsed_amd.features import MelConfig, MelFrontEnd
+    return MelFrontEnd(MelConfig(sr=22050))
+
+
+def _clips(n, seconds, sr=mo.SR):
+    return np.stack([mo.synth_clip(i, sr=sr, seconds=seconds)[0] for i in range(n)])
 
 
 @pytest.mark.parametrize("seconds", [1.0, 10.0])
-def test_linear_mel_matches_oracle(fe, seconds):
-    wav = _clips(3, seconds)
+@pytest.mark.parametrize("sr", [32000, 22050])
+def test_linear_mel_matches_oracle(fe, fe_m, seconds, sr):
+    wav = _clips(3, seconds, sr)
+    fe = fe if sr == 32000 else fe_m
+    assert fe.cfg.mel_f_max == min(16000.0, sr / 2)
     mel, cmax, sumsq = fe.linear(torch.from_numpy(wav).cuda())
     mel, cmax, sumsq = mel.cpu().numpy(), cmax.cpu().numpy(), sumsq.cpu().numpy()
     T = 1 + wav.shape[1] // 255
     assert mel.shape == (3, T, 128)
     for b in range(3):
-        ref = mo.preprocess(wav[b])
+        ref = mo.preprocess(wav[b], sr=sr, fmax=min(16000.0, sr / 2))
         err = np.abs(mel[b] - ref)
         tol = 2e-5 * ref.max() + 2e-5 * np.abs(ref)
         assert (err <= tol).all(), (err.max(), ref.max(), float((err / tol).max()))
@@ -59,6 +69,26 @@ def test_db_clamp_pad_and_noisy_view(fe):
             if (~live).any():
                 assert np.abs(got[0, :T][~live] - ref[0, :T][~live]).max() < 2e-3
             assert got[0, :T].min() >= got[0, :T].max() - 80.0 - 1e-4
+
+
+def test_bench_config_db_mel_matches_oracle(fe_m):
+    """the exact front end bench.py times: 10 s clips at 22.05 kHz -> 865 frames, dB with the per-clip top_db clamp,
+    clean and noisy (injected unit noise) views against the oracle's transform_pair"""
+    sr = 22050
+    wav = _clips(2, 10.0, sr)
+    T = 1 + wav.shape[1] // 255
+    assert T == 865
+    unit = np.random.default_rng(6).standard_normal((2, T, 128)).astype(np.float32)
+    clean, noisy = fe_m.transform(torch.from_numpy(wav).cuda(), max_frames=T, noisy=True,
+                                  unit_noise=torch.from_numpy(unit).cuda())
+    clean, noisy = clean.cpu().numpy(), noisy.cpu().numpy()
+    assert clean.shape == (2, 1, T, 128)
+    for b in range(2):
+        lin = mo.preprocess(wav[b], sr=sr, fmax=sr / 2)
+        ref_c, ref_n = mo.transform_pair(lin, T, unit_noise=unit[b])
+        for got, ref in ((clean[b], ref_c), (noisy[b], ref_n)):
+            assert np.abs(got - ref).max() < 2e-3
+            assert got.min() >= got.max() - 80.0 - 1e-4
 
 
 def test_truncation_and_silence(fe):

@@ -251,3 +251,71 @@ def test_oracle_crnn_fpn_matches_reference_golden(golden_dir):
     grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
     for n, ref_norm in zip(g["grad_names"], g["grad_norms"]):
         assert abs(float(grads[str(n)].double().norm()) - ref_norm) < 1e-4 * ref_norm + 1e-9, str(n)
+
+
+# ---------------------------------------------------------------- CRNN_pred (BASELINE configs[1]) and transforms
+def _cnn_pred_kwargs(dropout):
+    kw = dict(co.CRNN_KWARGS)
+    kw.update(nclass=128, n_RNN_cell=64, dropout=dropout)
+    return kw
+
+
+@pytest.mark.parametrize("tag", ["small", "R"])
+def test_oracle_cnn_pred_matches_reference_golden(golden_dir, tag):
+    g = _load(golden_dir, "cnn_pred.npz")
+    B, T, seed = (int(v) for v in g[f"{tag}_meta"])
+    x = torch.from_numpy(seeded.db_like_input(seed + 10, B, T))
+    m = co.CRNN_pred(**_cnn_pred_kwargs(0.5))
+    assert list(m.state_dict().keys()) == [str(n) for n in g["state_names"]]
+    vals = seeded.load_seeded(m, seed)
+    assert seeded.checksum(vals) == float(g[f"{tag}_weight_checksum"][0])
+    m.eval()
+    with torch.no_grad():
+        strong, weak = m(x)
+    np.testing.assert_allclose(strong.numpy(), g[f"{tag}_eval_strong"], atol=1e-6)
+    np.testing.assert_allclose(weak.numpy(), g[f"{tag}_eval_weak"], atol=1e-6)
+    m = co.CRNN_pred(**_cnn_pred_kwargs(0.0))
+    seeded.load_seeded(m, seed)
+    m.train()
+    with torch.no_grad():
+        strong, weak = m(x)
+    np.testing.assert_allclose(strong.numpy(), g[f"{tag}_train_strong"], atol=2e-6)
+    np.testing.assert_allclose(weak.numpy(), g[f"{tag}_train_weak"], atol=2e-6)
+    np.testing.assert_allclose(m.state_dict()["cnn.batchnorm6.running_var"].numpy(), g[f"{tag}_after_rv6"], rtol=1e-5)
+
+
+def test_oracle_transforms_match_reference_golden(golden_dir):
+    """a2 / a4: the restated gaussian_noise / pad_trunc_seq / pipeline against vectors produced by RUNNING the
+    reference's src/data/Transforms.py (numpy legacy RNG seeded identically)."""
+    g = _load(golden_dir, "transforms.npz")
+    x = g["x"]
+    np.random.seed(2023)
+    got = mo.gaussian_noise(x, 30.0, rng=np.random)
+    assert got.dtype == np.float64
+    np.testing.assert_allclose(got, g["noisy_snr30"], rtol=0, atol=1e-12)
+    std = mo.gaussian_noise_std(x, 30.0)
+    np.testing.assert_allclose(std, np.sqrt(np.mean((x.astype(np.float32) ** 2) * 1e-3, axis=0)), rtol=1e-6)
+    for key, n in (("pad50", 50), ("trunc20", 20), ("same37", 37)):
+        out = mo.pad_trunc_seq(x, n)
+        assert out.shape == g[key].shape and np.array_equal(out, g[key])
+    x3 = np.stack([x, 0.5 * x])
+    assert np.array_equal(mo.pad_trunc_seq(x3, 40), g["pad3d_40"])
+    for tag, frames in (("pad", 50), ("trunc", 20)):
+        np.random.seed(99)
+        clean, noisy = mo.transform_pair(x, frames, snr=30.0, unit_noise=np.random.normal(0, 1, x.shape))
+        assert clean.shape == g[f"pipe_{tag}_clean"].shape and clean.dtype == np.float32
+        np.testing.assert_allclose(clean, g[f"pipe_{tag}_clean"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(noisy, g[f"pipe_{tag}_noisy"], rtol=0, atol=1e-5)
+
+
+def test_oracle_fpn_weights_init_statistics(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "weights_init_fpn.json")))
+    torch.manual_seed(2023)
+    m = co.CRNN_fpn(**co.CRNN_KWARGS)
+    m.apply(co.weights_init)
+    sd = m.state_dict()
+    assert sorted(sd.keys()) == sorted(ref.keys())
+    for k, (mean, std, amax, asum) in ref.items():
+        v = sd[k].double()
+        assert abs(float(v.mean()) - mean) < 1e-5 + 1e-4 * abs(mean), k
+        assert abs(float(v.abs().sum()) - asum) < 1e-3 + 1e-4 * asum, k
