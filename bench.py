@@ -10,8 +10,9 @@ BCE strong + BCE weak -> backward -> (RCCL all-reduce of the flat gradient arena
 BASELINE.json configs[2] ("main_baseline.py full CRNN train step on SYN, batch 256 per GPU"), the
 configuration the metric is quoted on; data parallel = weak scaling (256 clips per GPU).
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant MFMA kernel, HIP-event timed inside the timed
-region) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample).
+Prints ONE JSON line on rank 0 with `roofline` (the kernel with the largest total time of the step, every
+launch HIP-event timed inside the timed region), `roofline_step` (whole-step fraction by SURVEY.md 8(d)'s formula)
+and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample, before the GPU is touched).
 """
 import argparse
 import json
@@ -65,36 +66,100 @@ def strong_labels(events, Tp, sr, hop, pooling, device):
     return y.to(device)
 
 
+def _cpu_mel_one(args):
+    """process-pool worker of cpu_baseline (module level so that it pickles): numpy mel + dB of one synthetic clip"""
+    i, sr, seconds = args
+    from threadpoolctl import threadpool_limits
+    from oracle import mel_oracle as mo
+    c = mo.synth_clip(i, sr=sr, seconds=seconds)[0]
+    T = 1 + len(c) // 255
+    with threadpool_limits(1):       # one BLAS thread per worker: the pool (or the caller's loop) owns the parallelism
+        return mo.transform_pair(mo.preprocess(c, sr=sr, fmax=min(16000.0, sr / 2)), T, unit_noise=np.zeros((T, 128)))[0]
+
+
 def cpu_baseline(sr, seconds, threads):
-    """The CPU oracle (numpy mel restatement + stock torch.nn CRNN train step) on this host's cores."""
+    """The CPU oracle on this host's cores, as SURVEY.md 8(d) specifies it: the numpy mel restatement on 16 clips
+    single-threaded and with a process pool, and the stock torch.nn CRNN train step (config 3) at B = 8 and B = 32 with
+    1 warm-up + 3 timed steps on all threads.  Runs BEFORE this process touches the GPU (the pool's workers are fresh
+    interpreters).  value = clips/s of pooled mel + the faster of the two train-step batch sizes."""
+    import multiprocessing as mp
     from oracle import crnn_oracle as co
     from oracle import mel_oracle as mo
-    torch.set_num_threads(threads)
-    n_mel = 4
-    clips = [mo.synth_clip(i, sr=sr, seconds=seconds)[0] for i in range(n_mel)]
+    n_mel = 16
     t0 = time.perf_counter()
-    mels = [mo.transform_pair(mo.preprocess(c, sr=sr, fmax=min(16000.0, sr / 2)), 1 + len(c) // 255,
-                              unit_noise=np.zeros((1 + len(c) // 255, 128)))[0] for c in clips]
-    t_mel = (time.perf_counter() - t0) / n_mel
-    B = 8
-    crnn, pred = co.build(seed=1, dropout=0.5)
-    crnn.train(); pred.train()
-    opt = torch.optim.Adam(list(crnn.parameters()) + list(pred.parameters()), lr=1e-3)
-    x = torch.from_numpy(np.stack([mels[i % n_mel] for i in range(B)]))
-    Tp = x.shape[2] // 4
-    y = torch.zeros((B, Tp, 20)); y[:, Tp // 3: Tp // 2, 3] = 1
-    times = []
-    for it in range(3):
+    mels = [_cpu_mel_one((i, sr, seconds)) for i in range(n_mel)]
+    t_mel_1 = (time.perf_counter() - t0) / n_mel
+    workers = max(1, min(threads, n_mel))
+    torch.set_num_threads(1)
+    with mp.get_context("spawn").Pool(workers) as pool:
+        pool.map(_cpu_mel_one, [(i, sr, 0.5) for i in range(workers)])          # start-up and imports, untimed
         t0 = time.perf_counter()
-        opt.zero_grad()
-        loss, _ = co.train_losses(crnn, pred, x, y)
-        loss.backward()
-        opt.step()
-        times.append(time.perf_counter() - t0)
-    t_step = float(np.mean(times[1:])) / B
-    return {"value": 1.0 / (t_mel + t_step), "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": f"numpy mel on {n_mel} clips (single thread, {t_mel*1e3:.0f} ms/clip) + torch CPU CRNN train "
-                      f"step B={B}, 1 warm-up + 2 timed ({t_step*1e3:.0f} ms/clip), {seconds:g} s clips @ {sr} Hz"}
+        pool.map(_cpu_mel_one, [(i, sr, seconds) for i in range(n_mel)], chunksize=1)
+        t_mel_p = (time.perf_counter() - t0) / n_mel
+    torch.set_num_threads(threads)
+    steps = {}
+    for B in (8, 32):
+        crnn, pred = co.build(seed=1, dropout=0.5)
+        crnn.train(); pred.train()
+        opt = torch.optim.Adam(list(crnn.parameters()) + list(pred.parameters()), lr=1e-3)
+        x = torch.from_numpy(np.stack([mels[i % n_mel] for i in range(B)]))
+        Tp = x.shape[2] // 4
+        y = torch.zeros((B, Tp, 20)); y[:, Tp // 3: Tp // 2, 3] = 1
+        times = []
+        for it in range(4):
+            t0 = time.perf_counter()
+            opt.zero_grad()
+            loss, _ = co.train_losses(crnn, pred, x, y)
+            loss.backward()
+            opt.step()
+            times.append(time.perf_counter() - t0)
+        steps[B] = float(np.mean(times[1:])) / B
+    t_step = min(steps.values())
+    t_mel_p = min(t_mel_p, t_mel_1)
+    return {"value": round(1.0 / (t_mel_p + t_step), 3), "unit": "clips/s", "cores": threads, "kind": "port",
+            "mel_clips_per_s_single_thread": round(1.0 / t_mel_1, 2), "mel_clips_per_s_pool": round(1.0 / t_mel_p, 2),
+            "train_step_clips_per_s": {f"B{b}": round(1.0 / v, 2) for b, v in steps.items()},
+            "sample": f"numpy mel+dB on {n_mel} clips: 1 thread {t_mel_1*1e3:.0f} ms/clip, pool of {workers} processes "
+                      f"{t_mel_p*1e3:.0f} ms/clip; torch CPU CRNN train step (oracle, fp32, {threads} threads), 1 warm-up "
+                      f"+ 3 timed steps: B=8 {steps[8]*1e3:.0f} ms/clip, B=32 {steps[32]*1e3:.0f} ms/clip; {seconds:g} s "
+                      f"clips @ {sr} Hz"}
+
+
+SPLIT_KERNEL = re.compile(r"3[a-z]?_kernel")      # *3_kernel / *3n / *3p / *3s: split-fp32 operands on the bf16 cores
+MFMA_KERNEL = re.compile(r"^(igemm|wgrad|glu_fwd3|glu_bwd3|glu_bwd_fused|gru_fwd_mfma|gru_bwd_mfma|glu16)")
+ALGORITHMIC_MB_PER_CLIP = {22050: 128.9, 32000: 186.9}     # SURVEY.md 8(d), fp32 activations, mel stage included
+STEP_GFLOP_PER_CLIP = {22050: 7.63, 32000: 11.05}           # SURVEY.md 8(d), train step = fwd + 2 x bwd
+
+
+def kernel_roofline(name, launches, total_ms, flops_total, bytes_total):
+    """roofline object of one kernel (template instance): which roof binds it and the achieved fraction.  The matrix
+    ceiling of a split-fp32 kernel is the dense bf16 peak / 3 (three bf16 MFMAs per fp32 product); fp32-core MFMA kernels
+    and plain VALU kernels share the 157.3 TFLOP/s fp32 ceiling."""
+    split = SPLIT_KERNEL.search(name) is not None
+    peak_tf = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS
+    avg_ms = total_ms / launches
+    tflops = flops_total / (total_ms * 1e-3) / 1e12
+    gbs = bytes_total / (total_ms * 1e-3) / 1e9
+    intensity = flops_total / max(bytes_total, 1.0)
+    ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+    on_matrix = MFMA_KERNEL.search(name) is not None
+    basis = ("dense bf16 MFMA 2500 / 3 (bf16x3 split-fp32 operands)" if split else
+             "fp32 MFMA 157.3 (v_mfma_f32_32x32x2_f32)" if on_matrix else "fp32 vector 157.3 (no matrix-core work in this kernel)")
+    r = {"traffic": None, "kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+         "algorithmic_gflop_per_launch": round(flops_total / launches / 1e9, 3),
+         "algorithmic_mbytes_per_launch": round(bytes_total / launches / 1e6, 2),
+         "intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
+         "compute_tflops": round(tflops, 2), "compute_peak_tflops": round(peak_tf, 1), "compute_peak_basis": basis,
+         "hbm_gbs": round(gbs, 1)}
+    if intensity >= ridge and on_matrix:
+        r.update({"bound": "mfma", "achieved": round(tflops, 3), "peak": round(peak_tf, 1), "unit": "TFLOP/s",
+                  "frac": round(tflops / peak_tf, 4)})
+    else:
+        r.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                  "frac": round(gbs / PEAK_HBM_GBS, 4)})
+        if intensity >= ridge:   # a VALU kernel above the ridge: the fp32 vector ceiling is the tighter roof
+            r["valu_frac"] = round(tflops / peak_tf, 4)
+    return r
 
 
 def main():
@@ -102,15 +167,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default 256; 64 for --mode cnn)")
     ap.add_argument("--sr", type=int, default=22050, help="22050 = BASELINE measurement config, 32000 = reference config")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--mode", choices=["crnn", "mt", "ada"], default="crnn",
+    ap.add_argument("--mode", choices=["crnn", "mt", "ada", "cnn"], default="crnn",
                     help="crnn = BASELINE configs[2] (the headline metric); mt = configs[3] (student + EMA teacher + "
-                         "consistency, half the batch synthetic, half real); ada = configs[4] (domain-adversarial head)")
+                         "consistency, half the batch synthetic, half real); ada = configs[4] (domain-adversarial head); "
+                         "cnn = configs[1] (CNN-only tagging forward, CRNN_pred, batch 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 64 if args.mode == "cnn" else 256
 
     t_start = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
@@ -119,6 +187,22 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    # CPU baseline first, on rank 0 at N = 1 only, BEFORE this process initialises the GPU: its process pool starts
+    # fresh interpreters, which a GPU-initialised parent must not do on the GPU boxes
+    cpu = None
+    if not args.no_cpu_baseline and world == 1 and args.mode == "crnn":
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncpu = os.cpu_count() or 1
+        cpu = cpu_baseline(args.sr, args.seconds, max(1, min(ncpu, 16)))
+        log(f"cpu baseline done: {cpu['value']} clips/s on {cpu['cores']} threads")
+
     ngpu = torch.cuda.device_count()
     # one process per GPU; BSED_DIST_BACKEND=gloo lets several ranks share one card for rehearsals of the N>1 path
     backend = os.environ.get("BSED_DIST_BACKEND", "nccl")
@@ -146,62 +230,71 @@ def main():
             os.close(saved_fd)
 
     from bsed_amd import ops
-    from bsed_amd.engine import FlatAdam, SEDTrainer
+    from bsed_amd.engine import FlatAdam, FlatSGD, SEDTrainer
     from bsed_amd.features import MelConfig, MelFrontEnd
-    from bsed_amd.models import CRNN, Predictor, weights_init
+    from bsed_amd.models import CRNN, CRNN_pred, Predictor, weights_init
 
     kw = dict(n_in_channel=1, nclass=20, attention=True, n_RNN_cell=128, n_layers_RNN=2, activation="glu",
               dropout=0.5, kernel_size=7 * [3], padding=7 * [1], stride=7 * [1],
               nb_filters=[16, 32, 64, 128, 128, 128, 128],
               pooling=[[2, 2], [2, 2], [1, 2], [1, 2], [1, 2], [1, 2], [1, 2]])
     torch.manual_seed(2023)
-    crnn, pred = CRNN(**kw), Predictor(nclass=20, attention=True, n_RNN_cell=128)
-    weights_init(crnn); weights_init(pred)
     mcfg = MelConfig(sr=args.sr)
     fe = MelFrontEnd(mcfg)
-    extra = {}
-    if args.mode == "mt":
-        # reference src/main_scmt.py: the teacher is a second CRNN/Predictor pair that only ever receives the EMA
-        ema_c, ema_p = CRNN(**kw), Predictor(nclass=20, attention=True, n_RNN_cell=128)
-        ema_c.load_state_dict(crnn.state_dict()); ema_p.load_state_dict(pred.state_dict())
-        extra = dict(ema_crnn=ema_c, ema_predictor=ema_p)
-    elif args.mode == "ada":
-        from bsed_amd.disc import Clip_Discriminator, ConditionalDomainAdversarialLoss
-        from bsed_amd.engine import FlatSGD
-        disc = Clip_Discriminator()
-        extra = dict(domain_loss=ConditionalDomainAdversarialLoss(disc),
-                     optimizer_d=FlatSGD([disc], lr=1e-4, momentum=0.9, weight_decay=0.0))
-    tr = SEDTrainer(crnn, pred, optimizer=FlatAdam([crnn, pred], lr=1e-3), frontend=fe, seed=2023, **extra)
-    tr.broadcast_parameters()
-
     B, n = args.batch, int(args.seconds * args.sr)
     wav, ev = synth_waves(B, n, args.sr, 2023 + rank, dev)
     T = fe.num_frames(n)
     Tp = T // 4
-    y = strong_labels(ev, Tp, args.sr, mcfg.hop_size, 4, dev)
+    tr = None
+    if args.mode == "cnn":
+        # BASELINE configs[1]: the reference's CNN-only tagger (CRNN_pred, models/CRNN_GRL.py:206-290) in eval mode:
+        # waveform -> mel/dB -> 7 conv blocks -> sigmoid features + class-softmax attention pooling
+        kwp = dict(kw); kwp.update(nclass=128, n_RNN_cell=64)
+        tagger = CRNN_pred(**kwp)
+        weights_init(tagger)
+        tagger.eval()
 
-    if args.mode == "crnn":
         def step():
-            return tr.train_step(wav, y, from_wave=True)
+            with torch.no_grad():
+                return tagger(fe.transform(wav, max_frames=T))
     else:
-        # half the clips play the synthetic (strongly labelled) batch, half the real batch (weak labels for mt)
-        h = B // 2
-        wav_s, y_s, wav_r = wav[:h].contiguous(), y[:h].contiguous(), wav[h:].contiguous()
-        yw_r = y[h:].max(1)[0].contiguous() if args.mode == "mt" else None
+        crnn, pred = CRNN(**kw), Predictor(nclass=20, attention=True, n_RNN_cell=128)
+        weights_init(crnn); weights_init(pred)
+        extra = {}
+        optimizer = FlatAdam([crnn, pred], lr=1e-3)
+        if args.mode == "mt":
+            # reference src/main_scmt.py: the teacher is a second CRNN/Predictor pair that only ever receives the EMA
+            ema_c, ema_p = CRNN(**kw), Predictor(nclass=20, attention=True, n_RNN_cell=128)
+            ema_c.load_state_dict(crnn.state_dict()); ema_p.load_state_dict(pred.state_dict())
+            extra = dict(ema_crnn=ema_c, ema_predictor=ema_p)
+        elif args.mode == "ada":
+            from bsed_amd.disc import Clip_Discriminator, ConditionalDomainAdversarialLoss
+            disc = Clip_Discriminator()
+            # reference src/main_scmt_ada_weak.py:854-866: SGD-Nesterov(momentum 0.9, weight decay 1e-4) for BOTH optimizers
+            optimizer = FlatSGD([crnn, pred], lr=1e-3, momentum=0.9, weight_decay=1e-4, nesterov=True)
+            extra = dict(domain_loss=ConditionalDomainAdversarialLoss(disc),
+                         optimizer_d=FlatSGD([disc], lr=1e-4, momentum=0.9, weight_decay=1e-4, nesterov=True))
+        tr = SEDTrainer(crnn, pred, optimizer=optimizer, frontend=fe, seed=2023, **extra)
+        tr.broadcast_parameters()
+        y = strong_labels(ev, Tp, args.sr, mcfg.hop_size, 4, dev)
+        if args.mode == "crnn":
+            def step():
+                return tr.train_step(wav, y, from_wave=True)
+        else:
+            # half the clips play the synthetic (strongly labelled) batch, half the real batch (weak labels for mt)
+            h = B // 2
+            wav_s, y_s, wav_r = wav[:h].contiguous(), y[:h].contiguous(), wav[h:].contiguous()
+            yw_r = y[h:].max(1)[0].contiguous() if args.mode == "mt" else None
 
-        def step():
-            return tr.train_step(wav_s, y_s, wav_r, yw_r, from_wave=True)
-
-    def log(msg):
-        if rank == 0:
-            print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+            def step():
+                return tr.train_step(wav_s, y_s, wav_r, yw_r, from_wave=True)
 
     log(f"data ready: B={B} n={n} T={T} Tp={Tp}")
     use_timer = not args.no_kernel_timer and rank == 0
     # The warm-up runs with a throw-away kernel timer: the first few hundred HIP events of a process make the runtime
     # grow its signal pool (a one-time ~45 ms stall, measured on a fresh box), which must not land in the timed region.
     if use_timer:
-        ops.KernelTimer.prime(2 * 120 * (args.steps + args.warmup) + 512)
+        ops.KernelTimer.prime(2 * 400 * (args.steps + args.warmup) + 512)
         ops.set_timer(ops.KernelTimer())
     for i in range(args.warmup):
         step()
@@ -229,7 +322,10 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax)
-    loss = SEDTrainer.loss_value(out)
+    if args.mode == "cnn":
+        loss = float(out[1].mean())      # mean weak probability: a finite-output check, not a loss
+    else:
+        loss = SEDTrainer.loss_value(out)
     if rank != 0:
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
@@ -237,93 +333,91 @@ def main():
 
     value = world * B * args.steps / elapsed
     roofline = None
-    kernels = {}
+    extra_fields = {}
     if timer is not None:
-        # {(kernel, taps, CIN, N, H, W): (launches, total_ms, avg_ms, flops_per_launch, algorithmic_bytes_per_launch)}
+        # {(kernel, shape tag): (launches, total_ms, avg_ms, flops_per_launch, algorithmic_bytes_per_launch)}
         summ = timer.summary()
         tot_ms = sum(v[1] for v in summ.values())
         for k in sorted(summ, key=lambda k: -summ[k][1]):
             c, tms, ams, fl, nb = summ[k]
-            log("  %-52s x%-3d %8.3f ms/step  avg %7.3f ms  %6.1f TFLOP/s %6.0f GB/s" % (
-                "%s t%d CIN%d N%d %dx%d" % k, c // args.steps, tms / args.steps, ams, fl / ams / 1e9, nb / ams / 1e6))
-        # the roofline object is quoted per KERNEL (template instance, the unit rocprofv3 --stats aggregates on):
-        # all its launches of the timed region, algorithmic FLOPs = 2 * positions * taps * CIN * N of each launch
+            log("  %-58s x%-3d %8.3f ms/step  avg %7.3f ms  %6.1f TFLOP/s %6.0f GB/s" % (
+                "%s %s" % k, c // args.steps, tms / args.steps, ams, fl / ams / 1e9, nb / ams / 1e6))
+        # the roofline object is quoted per KERNEL (template instance, the unit rocprofv3 --stats aggregates on): all its
+        # launches of the timed region with their algorithmic FLOPs and bytes; EVERY launch of the step is timed (mel,
+        # first block, BatchNorm, GRU, head, optimizer and glue included), so the kernel named is the step's dominant one
         byk = {}
         for k, (c, tms, ams, fl, nb) in summ.items():
             a = byk.setdefault(k[0], [0, 0.0, 0.0, 0.0])
             a[0] += c; a[1] += tms; a[2] += fl * c; a[3] += nb * c
         for name in sorted(byk, key=lambda n: -byk[n][1]):
             c, tms, fl, nb = byk[name]
-            log("  KERNEL %-34s x%-3d %8.3f ms/step  avg %7.3f ms  %6.1f TFLOP/s %6.0f GB/s" % (
+            log("  KERNEL %-40s x%-3d %8.3f ms/step  avg %7.3f ms  %6.1f TFLOP/s %6.0f GB/s" % (
                 name, c // args.steps, tms / args.steps, tms / c, fl / tms / 1e9, nb / tms / 1e6))
         name = max(byk, key=lambda n: byk[n][1])
-        launches, total_ms, flops_total, bytes_total = byk[name]
-        avg_ms = total_ms / launches
-        tflops = flops_total / (total_ms * 1e-3) / 1e12
-        gbs = bytes_total / (total_ms * 1e-3) / 1e9
-        # kernels named *3_kernel / *3n_kernel run split-fp32 operands on the bf16 matrix cores: 3 bf16 MFMAs per
-        # product, so their ceiling in algorithmic (fp32-equivalent) FLOP/s is the dense bf16 peak / 3
-        split = re.search(r"3[a-z]?_kernel", name) is not None
-        peak_tf = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS
-        # which roof bounds this kernel: its arithmetic intensity against the ridge point of ITS matrix-core ceiling
-        intensity = flops_total / max(bytes_total, 1.0)
-        ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
-        basis = ("dense bf16 MFMA 2500 / 3 (bf16x3 split-fp32 operands)" if split
-                 else "fp32 MFMA 157.3 (v_mfma_f32_32x32x2_f32)")
-        common = {"traffic": None, "kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
-                  "algorithmic_gflop_per_launch": round(flops_total / launches / 1e9, 3),
-                  "algorithmic_mbytes_per_launch": round(bytes_total / launches / 1e6, 2),
-                  "intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
-                  "mfma_tflops": round(tflops, 2), "mfma_peak_tflops": round(peak_tf, 1), "mfma_peak_basis": basis,
-                  "hbm_gbs": round(gbs, 1), "share_of_mfma_kernel_time": round(total_ms / tot_ms, 3),
-                  "mfma_kernels_ms_per_step": round(tot_ms / args.steps, 3)}
-        if intensity >= ridge:
-            roofline = {"bound": "mfma", "achieved": round(tflops, 3), "peak": round(peak_tf, 1), "unit": "TFLOP/s",
-                        "frac": round(tflops / peak_tf, 4)}
-        else:
-            roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(gbs / PEAK_HBM_GBS, 4)}
-        roofline.update(common)
-        all_flops = sum(v[0] * v[3] for v in summ.values())
-        kernels = {"all_mfma_kernels_tflops": round(all_flops / (tot_ms * 1e-3) / 1e12, 2)}
+        roofline = kernel_roofline(name, *byk[name])
+        roofline["share_of_kernel_time"] = round(byk[name][1] / tot_ms, 3)
+        roofline["kernels_ms_per_step"] = round(tot_ms / args.steps, 3)
         # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # passes, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for the profiled workload
         try:
             if args.mode == "crnn" and B == 256 and args.sr == 22050 and args.seconds == 10.0:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(name)
-                if pmc:
-                    roofline["traffic"] = round(pmc["hbm_bytes_per_launch"])
-                    roofline["traffic_source"] = "profiles/r01_pmc_traffic.json"
+                for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                    path = os.path.join(ROOT, "profiles", fn)
+                    if not os.path.exists(path):
+                        continue
+                    pmc = json.load(open(path))["kernels"].get(name)
+                    if pmc:
+                        roofline["traffic"] = round(pmc["hbm_bytes_per_launch"])
+                        roofline["traffic_source"] = "profiles/" + fn
+                        break
         except (OSError, KeyError, ValueError):
             pass
-    cpu = None
-    if not args.no_cpu_baseline:
-        try:
-            ncpu = len(os.sched_getaffinity(0))
-        except AttributeError:
-            ncpu = os.cpu_count() or 1
-        cpu = cpu_baseline(args.sr, args.seconds, max(1, min(ncpu, 16)))
-        log("cpu baseline done")
+        # the MFMA-bound kernel with the largest total, for continuity with round 1's line
+        mf = [nm for nm in byk if MFMA_KERNEL.search(nm) and
+              byk[nm][2] / max(byk[nm][3], 1.0) >= (PEAK_BF16_MFMA_TFLOPS / 3 if SPLIT_KERNEL.search(nm) else
+                                                    PEAK_FP32_MFMA_TFLOPS) * 1e12 / (PEAK_HBM_GBS * 1e9)]
+        if mf:
+            nm = max(mf, key=lambda n: byk[n][1])
+            extra_fields["roofline_top_mfma_kernel"] = {k: v for k, v in kernel_roofline(nm, *byk[nm]).items()
+                                                        if k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
+                                                                 "avg_launch_ms", "launches")}
+    if args.mode != "cnn" and args.sr in ALGORITHMIC_MB_PER_CLIP:
+        # whole-step fractions by SURVEY.md 8(d)'s formula: clips/s/GPU x algorithmic bytes (FLOPs) per clip over the peak
+        per_gpu = value / world
+        scale = {"crnn": 1.0, "mt": None, "ada": None}[args.mode]
+        if scale is not None:
+            mb, gf = ALGORITHMIC_MB_PER_CLIP[args.sr] * args.seconds / 10.0, STEP_GFLOP_PER_CLIP[args.sr] * args.seconds / 10.0
+            extra_fields["roofline_step"] = {
+                "bound": "hbm", "algorithmic_mb_per_clip": round(mb, 1), "achieved": round(per_gpu * mb / 1e3, 1),
+                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(per_gpu * mb * 1e6 / (PEAK_HBM_GBS * 1e9), 4),
+                "step_gflop_per_clip": gf, "tflops": round(per_gpu * gf / 1e3, 1),
+                "mfma_frac_bf16x3": round(per_gpu * gf * 1e9 / (PEAK_BF16_MFMA_TFLOPS / 3 * 1e12), 4)}
     workload = {
         "crnn": "waveform->STFT/mel/dB->CRNN(7 conv/BN/GLU/pool + 2xBiGRU128)->Predictor->BCE strong+weak"
                 "->backward->Adam; BASELINE configs[2] (main_baseline.py train step on SYN)",
         "mt": "mean teacher: student on B/2 synthetic + B/2 real clips, EMA teacher forward on the noisy real half, "
               "consistency MSE, backward, Adam, EMA update; BASELINE configs[3] (main_scmt.py)",
         "ada": "domain-adversarial: student on B/2 synthetic + B/2 real clips, Clip_Discriminator + gradient reverse "
-               "on both encodings, backward, Adam + SGD(discriminator); BASELINE configs[4] (main_scmt_ada_weak.py)",
+               "on both encodings, backward, SGD-Nesterov(0.9, wd 1e-4) on CRNN+Predictor and on the discriminator; "
+               "BASELINE configs[4] (main_scmt_ada_weak.py)",
+        "cnn": "waveform->STFT/mel/dB->7 conv/BN/GLU/pool blocks->sigmoid features + class-softmax attention pooling, "
+               "eval-mode forward only; BASELINE configs[1] (CNN-only tagging forward: the reference's CRNN_pred)",
     }[args.mode]
     line = {
-        "metric": "10 s clips/sec through mel+CRNN train step", "value": round(value, 2), "unit": "clips/s",
+        "metric": "10 s clips/sec through mel+CRNN train step" if args.mode != "cnn"
+                  else "10 s clips/sec through mel+CNN tagging forward",
+        "value": round(value, 2), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "contraction_mode": os.environ.get("BSED_CONV_MODE", "bf16x3"),
         "config": {"workload": workload, "mode": args.mode,
                    "clip_seconds": args.seconds, "sr": args.sr, "frames": T, "out_frames": Tp,
-                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "dropout": 0.5},
+                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "dropout": 0.0 if args.mode == "cnn" else 0.5},
         "roofline": roofline, "cpu_baseline": cpu, "final_loss": round(loss, 5),
     }
-    line.update(kernels)
+    line.update(extra_fields)
     print(json.dumps(line))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

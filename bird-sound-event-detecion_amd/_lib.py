@@ -93,10 +93,23 @@ def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Per-launch timing hook (bench.py's roofline leg): ``timer`` is an ops.KernelTimer or None.  A wrapper that knows the
+# algorithmic work of its launch announces it through ``pending`` = (key, flops, bytes) right before ``call``; launches
+# nobody announced are recorded under their entry-point name with zero work (small glue kernels).
+timer = None
+pending = None
+
+
 def call(name, *args):
     """Call an int-returning entry point; ints/floats are passed with explicit ctypes."""
+    global pending
     fn = getattr(lib(), name)
-    check(fn(*args), name)
+    if timer is None:
+        check(fn(*args), name)
+        return
+    meta, pending = pending, None
+    key, flops, nbytes = meta if meta is not None else ((name, ""), 0.0, 0.0)
+    timer.launch(key, flops, lambda: check(fn(*args), name), nbytes)
 
 
 c_int = ctypes.c_int

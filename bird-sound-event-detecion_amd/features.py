@@ -14,6 +14,7 @@ import math
 import torch
 
 from . import _lib as L
+from . import ops
 
 
 class MelConfig:
@@ -39,6 +40,7 @@ class MelFrontEnd:
                      self.cfg.mel_f_min, self.cfg.mel_f_max)
         self._plan = ctypes.c_void_p()
         L.call("bsed_mel_plan_create", ctypes.byref(c), ctypes.byref(self._plan))
+        self.nnz = int(L.lib().bsed_mel_plan_nnz(self._plan))
 
     def __del__(self):
         try:
@@ -60,6 +62,10 @@ class MelFrontEnd:
         mel = torch.empty((B, T, self.cfg.n_mels), device=wav.device, dtype=torch.float32)
         cmax = torch.empty((B,), device=wav.device, dtype=torch.float32)
         sumsq = torch.empty((B, self.cfg.n_mels), device=wav.device, dtype=torch.float32)
+        # algorithmic work: wave in + linear mel out; per frame a 2048-point real FFT (2.5 N log2 N), 1025
+        # magnitudes and the sparse filterbank
+        ops._note("stft_mel_kernel", f"T{T}", B * T * (2.5 * 2048 * 11 + 4.0 * 1025 + 2.0 * self.nnz),
+                  4.0 * B * (n + T * self.cfg.n_mels))
         L.call("bsed_mel_linear", self._plan, L.ptr(wav), L.c_int(B), L.c_int(n), L.ptr(mel), L.ptr(cmax),
                L.ptr(sumsq), L.stream())
         return mel, cmax, sumsq
@@ -77,6 +83,7 @@ class MelFrontEnd:
         B, T, M = mel_lin.shape
         T_out = T if max_frames is None else max_frames
         out = torch.empty((B, 1, T_out, M), device=mel_lin.device, dtype=torch.float32)
+        ops._note("mel_db_kernel", f"T{T_out}", 4.0 * B * T_out * M, 4.0 * B * M * (T + T_out))
         L.call("bsed_mel_db", L.ptr(mel_lin), L.ptr(clip_max), L.c_int(B), L.c_int(T), L.c_int(T_out),
                L.c_int(M), L.c_float(self.cfg.top_db), L.ptr(out), L.stream())
         return out
@@ -85,6 +92,7 @@ class MelFrontEnd:
         B, T, M = mel_lin.shape
         noisy = torch.empty_like(mel_lin)
         cmax = torch.empty((B,), device=mel_lin.device, dtype=torch.float32)
+        ops._note("mel_noise_kernel", f"T{T}", 30.0 * B * T * M, 8.0 * B * T * M)
         L.call("bsed_mel_noise", L.ptr(mel_lin), L.ptr(bin_sumsq), L.ptr(unit_noise), L.c_int(B), L.c_int(T),
                L.c_int(M), L.c_float(self.cfg.noise_snr), L.c_u64(seed), L.ptr(noisy), L.ptr(cmax), L.stream())
         return noisy, cmax

@@ -181,16 +181,15 @@ class CRNN(_FlatModule):
         return [], [], []
 
     def _gru_roles(self, prefix):
-        """GRU tensors in nn.GRU.parameters() order (the order the reference's weights_init walks them in)"""
-        out = []
-        for l in range(self.n_layers):
-            for sfx in ("", "_reverse"):
-                out += [(f"{prefix}.rnn.weight_ih_l{l}{sfx}", "gru"), (f"{prefix}.rnn.weight_hh_l{l}{sfx}", "gru"),
-                        (f"{prefix}.rnn.bias_ih_l{l}{sfx}", "gru"), (f"{prefix}.rnn.bias_hh_l{l}{sfx}", "gru")]
-        return out
+        return [(prefix, "gru")]
+
+    def _gru_matrices(self, prefix):
+        """the >= 2-D GRU tensors in nn.GRU.parameters() order (the order the reference's weights_init walks them in)"""
+        return [f"{prefix}.rnn.weight_{kind}_l{l}{sfx}" for l in range(self.n_layers) for sfx in ("", "_reverse")
+                for kind in ("ih", "hh")]
 
     def _init_roles(self):
-        """[(module prefix or GRU tensor, role)] in the order ``reference_model.apply(weights_init)`` visits the
+        """[(module prefix, role)] in the order ``reference_model.apply(weights_init)`` visits the
         modules that own parameters (src/models/CNN.py:43-69, src/models/CRNN_GRL.py:144-173): what a tensor IS
         (conv / bn / linear / gru) is recorded here, not guessed from its name."""
         order = []
@@ -802,11 +801,14 @@ def weights_init(m):
     with torch.no_grad():
         for name, role in order:
             if role == "gru":
-                p = m.P(name)
-                if p.dim() > 1:
-                    t = torch.empty(p.shape)
-                    nn.init.orthogonal_(t)
-                    p.copy_(t)
+                # the reference matches class names by substring: apply() reaches nn.GRU ("GRU") and then its wrapper
+                # BidirectionalGRU (also contains "GRU"), so every matrix is drawn twice and the second draw stays
+                for _ in range(2):
+                    for mat in m._gru_matrices(name):
+                        p = m.P(mat)
+                        t = torch.empty(p.shape)
+                        nn.init.orthogonal_(t)
+                        p.copy_(t)
                 continue
             w, b = m.P(name + ".weight"), m.P(name + ".bias")
             if role == "conv":

@@ -43,11 +43,14 @@ TAPS3x3 = [(kh - 1, kw - 1) for kh in range(3) for kw in range(3)]
 
 
 class KernelTimer:
-    """Optional per-launch HIP-event timing of the MFMA kernels (bench.py's roofline leg).  Events are
-    recorded on the stream the kernels are launched on (torch's current stream)."""
+    """Per-launch HIP-event timing of EVERY entry-point call of a step (bench.py's roofline leg).  Events are recorded
+    on the stream the kernels are launched on (torch's current stream).  key = (kernel label, shape tag): the label is
+    the kernel's name as rocprofv3 prints it (template instance included) so that bench.py's table and the committed
+    rocprof summary can be joined by name."""
 
     def __init__(self):
         self.records = {}  # key -> [flops_per_launch, [(start, end), ...], algorithmic_bytes_per_launch]
+        self._last, self._chain = None, False
 
     @staticmethod
     def prime(n=4096):
@@ -61,12 +64,24 @@ class KernelTimer:
         del evs
 
     def launch(self, key, flops, fn, nbytes):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
+        """One event per launch: on an in-order stream that the host keeps fed, the event recorded after launch i is also
+        the start of launch i+1 (half the events of a start/end pair per launch: each event costs the GPU ~1.5 us).  A
+        launch that follows anything other than a timed launch (the first of a step: host-side work in between) gets
+        its own start event."""
+        s = self._last if self._chain else None
+        if s is None:
+            s = torch.cuda.Event(enable_timing=True)
+            s.record()
         fn()
+        e = torch.cuda.Event(enable_timing=True)
         e.record()
+        self._last, self._chain = e, True
         rec = self.records.setdefault(key, [flops, [], nbytes])
         rec[1].append((s, e))
+
+    def break_chain(self):
+        """call between steps (or around host-side work): the next launch records its own start event"""
+        self._chain = False
 
     def summary(self):
         """{key: (launches, total_ms, avg_ms, flops_per_launch, bytes_per_launch)} -- call after a device sync"""
@@ -77,25 +92,29 @@ class KernelTimer:
         return out
 
 
-_timer = None
-
-
 def set_timer(t):
-    global _timer
-    _timer = t
+    L.timer = t
 
 
 def _launch(key, flops, fn, nbytes=None):
-    """key = (kernel, taps, CIN, N, H, W).  nbytes = ALGORITHMIC HBM bytes of the launch (each activation tensor the
-    op must read or write, once; weights and partial slabs not counted); default: a (positions, CIN) input and a
-    (positions, N) output in fp32, positions recovered from the FLOP count."""
-    if _timer is None:
-        fn()
-    else:
+    """Announce the algorithmic work of the entry-point call ``fn`` makes.  key = (kernel, taps, CIN, N, H, W) for the
+    contraction kernels or (kernel, tag) for the others.  nbytes = ALGORITHMIC HBM bytes of the launch (each activation
+    tensor the op must read or write, once; weights and partial slabs not counted); default: a (positions, CIN) input
+    and a (positions, N) output in fp32, positions recovered from the FLOP count."""
+    if L.timer is not None:
         if nbytes is None:
             _, taps, cin, n, _, _ = key
             nbytes = 4.0 * (flops / (2.0 * taps * cin * n)) * (cin + n)
-        _timer.launch(key, flops, fn, nbytes)
+        if len(key) == 6:
+            key = (key[0], "t%d CIN%d N%d %dx%d" % tuple(key[1:]))
+        L.pending = (key, float(flops), float(nbytes))
+    fn()
+
+
+def _note(kernel, tag, flops, nbytes):
+    """announce the next L.call (for wrappers whose call is written inline)"""
+    if L.timer is not None:
+        L.pending = ((kernel, tag), float(flops), float(nbytes))
 
 
 def round_up(v, m):
@@ -119,6 +138,7 @@ def _dp(t, offset=0):
 def pack_weight(src, ntaps, K, N, s_tap, s_k, s_n, src_offset=0):
     NP = round_up(N, 32)
     dst = torch.empty((ntaps, K, NP), device=src.device, dtype=torch.float32)
+    _note("pack_weight_kernel", "", 0.0, 4.0 * dst.numel())
     L.call("bsed_pack_weight", _fp(_dp(src, src_offset)), L.ptr(dst), _i(ntaps), _i(K), _i(N), _i(NP),
            ctypes.c_long(s_tap), ctypes.c_long(s_k), ctypes.c_long(s_n), L.stream())
     return dst
@@ -170,6 +190,7 @@ def pack_weight3(src, ntaps, K, N, s_tap, s_k, s_n):
     """bf16 hi/lo split weights for igemm3: uint16 (ntaps, K/32, NP, 64)"""
     NP = round_up(N, 32)
     dst = torch.empty((ntaps, K // 32, NP, 64), device=src.device, dtype=torch.int16)
+    _note("pack_weight3_kernel", "", 0.0, 4.0 * dst.numel())
     L.call("bsed_pack_weight3", _fp(_dp(src)), ctypes.c_void_p(dst.data_ptr()), _i(ntaps), _i(K), _i(N), _i(NP),
            ctypes.c_long(s_tap), ctypes.c_long(s_k), ctypes.c_long(s_n), L.stream())
     return dst
@@ -179,6 +200,7 @@ def pack_weight3s(src, ntaps, N, s_tap, s_k, s_n, K=16):
     """pre-split weights of a CIN = 16 / 32 convolution in fragment order: int16 (NP/32, ntaps, K/16, 2, 64, 8)"""
     NP = round_up(N, 32)
     dst = torch.empty((NP // 32, ntaps, K // 16, 2, 64, 8), device=src.device, dtype=torch.int16)
+    _note("pack_weight3s_kernel", "", 0.0, 4.0 * dst.numel())
     L.call("bsed_pack_weight3s", _fp(_dp(src)), ctypes.c_void_p(dst.data_ptr()), _i(ntaps), _i(K), _i(N), _i(NP),
            ctypes.c_long(s_tap), ctypes.c_long(s_k), ctypes.c_long(s_n), L.stream())
     return dst
@@ -293,6 +315,7 @@ def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=Non
 
 
 def reduce_partials(part, G, ntaps, KP, NP, K, N, dst, s_tap, s_k, s_n, accumulate=True, dst_offset=0):
+    _note("reduce_partials_kernel", f"G{G}", float(part.numel()), 4.0 * part.numel())
     L.call("bsed_reduce_partials", L.ptr(part), _i(G), _i(ntaps), _i(KP), _i(NP), _i(K), _i(N),
            _fp(_dp(dst, dst_offset)), ctypes.c_long(s_tap), ctypes.c_long(s_k), ctypes.c_long(s_n),
            _i(1 if accumulate else 0), L.stream())
@@ -317,6 +340,7 @@ def conv0_fwd(x, w, bias, NB, H, W, CO, want_stats):
     nt = L.lib().bsed_conv0_num_tiles(NB, H, W)
     if want_stats:
         stats = torch.empty((nt, 2, CO), device=x.device, dtype=torch.float32)
+    _note(f"conv0_fwd_kernel<{CO}>", f"{H}x{W}", 2.0 * 9 * CO * NB * H * W, 4.0 * NB * H * W * (1 + CO))
     L.call("bsed_conv0_fwd", L.ptr(x), _fp(_dp(w)), _fp(_dp(bias)), L.ptr(y), _fp(_p(stats)), _i(NB), _i(H), _i(W),
            _i(CO), L.stream())
     return y, stats
@@ -326,6 +350,9 @@ def conv0_wgrad(x, dy, NB, H, W, CO, y=None, coef=None, mean=None):
     """y/coef/mean given: dy is dL/d(BatchNorm output) and BatchNorm's backward is applied on load"""
     G = min(1024, max(1, (NB * H * W) // 256))
     part = torch.empty((G, 9, CO), device=x.device, dtype=torch.float32)
+    # x, dy (= g) and, with the fused BatchNorm backward, y: each read once
+    _note(f"conv0_wgrad_kernel<{CO}, {'true' if y is not None else 'false'}>", f"{H}x{W}",
+          2.0 * 9 * CO * NB * H * W, 4.0 * NB * H * W * (1 + CO * (2 if y is not None else 1)))
     L.call("bsed_conv0_wgrad", L.ptr(x), L.ptr(dy), _fp(_p(y)), _fp(_p(coef)), _fp(_p(mean)), L.ptr(part), _i(G),
            _i(NB), _i(H), _i(W), _i(CO), L.stream())
     return part, G
@@ -334,6 +361,7 @@ def conv0_wgrad(x, dy, NB, H, W, CO, y=None, coef=None, mean=None):
 def glu16_fwd(y, scale, shift, wg, bg, B, H, W, pool, drop_p, rng_stream, seed):
     ph, pw = pool
     out = torch.empty((B, H // ph, W // pw, 16), device=y.device, dtype=torch.float32)
+    _note("glu16_fwd_kernel", f"{H}x{W}", 2.0 * B * H * W * 256, 4.0 * B * H * W * 16 * (1.0 + 1.0 / (ph * pw)))
     L.call("bsed_glu16_fwd", L.ptr(y), L.ptr(scale), L.ptr(shift), _fp(_dp(wg)), _fp(_dp(bg)), L.ptr(out), _i(B), _i(H),
            _i(W), _i(16), _i(ph), _i(pw), ctypes.c_float(drop_p), ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed),
            L.stream())
@@ -349,6 +377,7 @@ def glu16_bwd(y, scale, shift, wg, bg, dpool, B, H, W, pool, drop_p, rng_stream,
     part_dw = torch.empty((G, 16, 16), device=dev, dtype=torch.float32)
     part_db = torch.empty((G, 2, 16), device=dev, dtype=torch.float32)
     part_st = torch.empty((G, 2, 16), device=dev, dtype=torch.float32)
+    _note("glu16_bwd_kernel", f"{H}x{W}", 3 * 2.0 * B * H * W * 256, 4.0 * B * H * W * 16 * (2.0 + 1.0 / (ph * pw)))
     L.call("bsed_glu16_bwd", L.ptr(y), L.ptr(scale), L.ptr(shift), _fp(_dp(wg)), _fp(_dp(bg)), L.ptr(dpool), L.ptr(g),
            L.ptr(part_dw), L.ptr(part_db), L.ptr(part_st), _i(G), _i(B), _i(H), _i(W), _i(16), _i(ph), _i(pw),
            ctypes.c_float(drop_p), ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream())
@@ -452,6 +481,7 @@ def glu_bwd3n(y, scale, shift, w, bias, dpool, B, H, W, C, pool, drop_p, rng_str
 def bn_finalize(stats, C, count, eps, momentum, gamma, beta, rmean, rvar, nbt):
     dev = stats.device
     mean, invstd, scale, shift = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(4))
+    _note("stats_chunk_kernel+stats_finish_kernel", f"C{C}", 0.0, 4.0 * stats.numel())
     L.call("bsed_bn_finalize", L.ptr(stats), ctypes.c_long(stats.shape[0]), _i(C), ctypes.c_double(count),
            ctypes.c_float(eps), ctypes.c_float(momentum), _fp(_dp(gamma)), _fp(_dp(beta)), _fp(_dp(rmean)),
            _fp(_dp(rvar)), _fp(None if nbt is None else nbt.data_ptr()), L.ptr(mean), L.ptr(invstd), L.ptr(scale),
@@ -472,6 +502,8 @@ def bn_bwd(stats, C, count, gamma, mean, invstd, dgamma, dbeta, g_inout, y, appl
     the consumer applies the map on load (conv0_wgrad)."""
     dev = y.device
     coef = torch.empty((3, C), device=dev, dtype=torch.float32)
+    _note("bn_bwd_apply_kernel" if apply else "stats_chunk_kernel+stats_finish_kernel", f"C{C}", 3.0 * y.numel() if apply else 0.0,
+          12.0 * y.numel() if apply else 4.0 * stats.numel())
     L.call("bsed_bn_bwd", L.ptr(stats), ctypes.c_long(stats.shape[0]), _i(C), ctypes.c_double(count), _fp(_dp(gamma)),
            L.ptr(mean), L.ptr(invstd), _fp(_dp(dgamma)), _fp(_dp(dbeta)), _i(1),
            L.ptr(g_inout) if apply else None, L.ptr(y) if apply else None,
@@ -480,6 +512,7 @@ def bn_bwd(stats, C, count, gamma, mean, invstd, dgamma, dbeta, g_inout, y, appl
 
 
 def stats_to_grad(stats, C, which, dst):
+    _note("stats_chunk_kernel+stats_finish_kernel", f"C{C}", 0.0, 4.0 * stats.numel())
     L.call("bsed_stats_to_grad", L.ptr(stats), ctypes.c_long(stats.shape[0]), _i(C), _i(which), _fp(_dp(dst)), _i(1),
            L.ptr(stats_scratch(C, stats.device), torch.float64), L.stream())
 
@@ -487,12 +520,14 @@ def stats_to_grad(stats, C, which, dst):
 def colsum(inp, M, C, pitch, dst, accumulate=True, in_offset=0):
     G = int(min(512, M))
     part = torch.empty((G, 2, C), device=inp.device, dtype=torch.float32)
+    _note("colsum_kernel", f"C{C}", float(M) * C, 4.0 * M * C)
     L.call("bsed_colsum", _fp(_dp(inp, in_offset)), ctypes.c_long(M), _i(C), _i(pitch), L.ptr(part), _i(G),
            _fp(_dp(dst)), _i(1 if accumulate else 0), L.ptr(stats_scratch(C, inp.device), torch.float64), L.stream())
 
 
 def dropout(x, p, rng_stream, seed):
     out = torch.empty_like(x)
+    _note("dropout_kernel", "", float(x.numel()), 8.0 * x.numel())
     L.call("bsed_dropout", L.ptr(x), L.ptr(out), ctypes.c_long(x.numel()), ctypes.c_float(p),
            ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream())
     return out
@@ -506,6 +541,8 @@ def gru_rows(B):
 def gru_fwd(xp, w_hh, b_hh, B, T, save_gates, mode="fp32"):
     out = torch.empty((B, T, 256), device=xp.device, dtype=torch.float32)
     gates = torch.empty((B, T, 2, 4, 128), device=xp.device, dtype=torch.float32) if save_gates else None
+    _note("gru_fwd_mfma_kernel<true>" if mode == "bf16x3" else "gru_fwd_kernel", f"T{T}", 2.0 * B * T * 2 * 128 * 384,
+          4.0 * B * T * (768 + 256 + (1024 if save_gates else 0)))
     if mode == "bf16x3":  # matrix-core recurrence, split-fp32 operands
         L.call("bsed_gru_fwd3", L.ptr(xp), _fp(_dp(w_hh)), _fp(_dp(b_hh)), L.ptr(out), _fp(_p(gates)), _i(B), _i(T),
                L.stream())
@@ -518,6 +555,8 @@ def gru_fwd(xp, w_hh, b_hh, B, T, save_gates, mode="fp32"):
 def gru_bwd(dout, out, gates, w_hh, B, T, mode="fp32"):
     dxp = torch.empty((B, T, 768), device=dout.device, dtype=torch.float32)
     dgh = torch.empty((B, T, 768), device=dout.device, dtype=torch.float32)
+    _note("gru_bwd_mfma_kernel" if mode == "bf16x3" else "gru_bwd_kernel", f"T{T}", 2.0 * B * T * 2 * 128 * 384,
+          4.0 * B * T * (256 + 256 + 1024 + 768 + 768))
     if mode == "bf16x3":
         rows = L.lib().bsed_gru_bwd3_rows(B)
         pih = torch.empty((rows, 768), device=dout.device, dtype=torch.float32)
@@ -539,6 +578,7 @@ def head_fwd(x, w, b, B, T, K, C, attention):
     den = torch.empty((B, C), device=dev, dtype=torch.float32)
     S = L.lib().bsed_head_splits(B, T)
     part = torch.empty((B, S, 2, C), device=dev, dtype=torch.float32) if S > 1 else None
+    _note(f"head_fwd_kernel<{C}>", f"T{T}", 2.0 * B * T * K * 2 * C, 4.0 * B * T * (K + 2 * C))
     L.call("bsed_head_fwd", L.ptr(x), _fp(_dp(w)), _fp(_dp(b)), L.ptr(strong), L.ptr(sof), L.ptr(weak), L.ptr(den),
            L.ptr(part), _i(B), _i(T), _i(K), _i(C), _i(1 if attention else 0), L.stream())
     return strong, sof, weak, den
@@ -564,6 +604,7 @@ def head_bwd(x, w, strong, sof, weak, den, B, T, K, C, attention, y_strong=None,
     d.inv_n_weak = 1.0 / (n_weak if n_weak else B * C)
     d.dx = _p(dx); d.dw_part = _p(dw_part); d.db_part = _p(db_part); d.loss_part = _p(loss_part)
     d.B, d.T, d.K, d.C, d.attention = B, T, K, C, 1 if attention else 0
+    _note(f"head_bwd_kernel<{C}>", f"T{T}", 3 * 2.0 * B * T * K * 2 * C, 4.0 * B * T * (2 * K + 4 * C))
     L.call("bsed_head_bwd", ctypes.byref(d), L.stream())
     return dx, dw_part, db_part, loss_part
 
@@ -575,18 +616,21 @@ def tag_head_fwd(x, logits):
     strong = torch.empty_like(x)
     weak = torch.empty((B, C), device=x.device, dtype=torch.float32)
     part = torch.empty((B, S, 2, C), device=x.device, dtype=torch.float32)
+    _note("tag_pool_kernel", f"T{T}", 12.0 * B * T * C, 12.0 * B * T * C)
     L.call("bsed_tag_head_fwd", L.ptr(x), L.ptr(logits), L.ptr(strong), L.ptr(weak), L.ptr(part), _i(B), _i(T), _i(C),
            L.stream())
     return strong, weak
 
 
 def adam_step(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    _note("adam_kernel", "", 12.0 * p.numel(), 28.0 * p.numel())
     L.call("bsed_adam_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), ctypes.c_long(p.numel()), ctypes.c_float(lr),
            ctypes.c_float(betas[0]), ctypes.c_float(betas[1]), ctypes.c_float(eps), ctypes.c_float(weight_decay),
            ctypes.c_long(step), ctypes.c_float(grad_scale), L.stream())
 
 
 def sgd_step(p, g, buf, lr, momentum, weight_decay, first_step, nesterov=True, grad_scale=1.0):
+    _note("sgd_kernel", "", 6.0 * p.numel(), 20.0 * p.numel())
     L.call("bsed_sgd_step", L.ptr(p), L.ptr(g), L.ptr(buf), ctypes.c_long(p.numel()), ctypes.c_float(lr),
            ctypes.c_float(momentum), ctypes.c_float(weight_decay), _i(1 if first_step else 0),
            _i(1 if nesterov else 0), ctypes.c_float(grad_scale), L.stream())
@@ -595,6 +639,7 @@ def sgd_step(p, g, buf, lr, momentum, weight_decay, first_step, nesterov=True, g
 def roll(x, B, H, W, sh=None, sw=None):
     """per-sample torch.roll of a contiguous (B,H,W[,..]) tensor viewed as (B,H,W); sh/sw: int32 device tensors (B)"""
     out = torch.empty_like(x)
+    _note("roll_kernel", "", 0.0, 8.0 * x.numel())
     L.call("bsed_roll", L.ptr(x), L.ptr(out), _i(B), _i(H), _i(W), L.ptr(sh, torch.int32), L.ptr(sw, torch.int32),
            L.stream())
     return out
@@ -602,11 +647,13 @@ def roll(x, B, H, W, sh=None, sw=None):
 
 def axpy(y, x, a=1.0):
     """y += a * x in place (contiguous fp32 tensors of equal size)"""
+    _note("axpy_kernel", "", 2.0 * y.numel(), 12.0 * y.numel())
     L.call("bsed_axpy", L.ptr(y), L.ptr(x.contiguous()), ctypes.c_long(y.numel()), ctypes.c_float(a), L.stream())
     return y
 
 
 def ema_update(ema, p, alpha):
+    _note("ema_kernel", "", 3.0 * p.numel(), 12.0 * p.numel())
     L.call("bsed_ema_update", L.ptr(ema), L.ptr(p), ctypes.c_long(p.numel()), ctypes.c_float(alpha), L.stream())
 
 

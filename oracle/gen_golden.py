@@ -223,8 +223,8 @@ def clipd_case():
 
 
 def init_case():
-    torch.manual_seed(2023)
     crnn, pred = CRNN(**CRNN_KWARGS), Predictor(**PREDICTOR_KWARGS)
+    torch.manual_seed(2023)         # seeded AFTER construction: the draws below are weights_init's alone
     crnn.apply(weights_init)
     pred.apply(weights_init)
     stats = {}
@@ -356,8 +356,8 @@ def transforms_case():
 def fpn_init_case():
     """per-tensor statistics of the reference's CRNN_fpn after .apply(weights_init) (utilities/utils.py:40-63)"""
     from models.CRNN_GRL import CRNN_fpn as RefFPN
-    torch.manual_seed(2023)
     m = RefFPN(**CRNN_KWARGS)
+    torch.manual_seed(2023)         # seeded AFTER construction: the draws below are weights_init's alone
     m.apply(weights_init)
     stats = {}
     for k, v in m.state_dict().items():
