@@ -6,8 +6,10 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 mkdir -p obj
 pids=()
+objs=()
 for f in *.hip; do
   o=obj/${f%.hip}.o
+  objs+=("$o")
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ bsed_common.h -nt "$o" ] || [ ../../include/bsed.h -nt "$o" ] \
      || { [ -f igemm_core.h ] && [ igemm_core.h -nt "$o" ]; }; then
     $HIPCC $FLAGS -c "$f" -o "$o" &
@@ -15,5 +17,5 @@ for f in *.hip; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libbsed.so obj/*.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libbsed.so "${objs[@]}"
 echo "built $(realpath ../libbsed.so)"

@@ -66,8 +66,11 @@ class MelFrontEnd:
         # magnitudes and the sparse filterbank
         ops._note("stft_mel_kernel", f"T{T}", B * T * (2.5 * 2048 * 11 + 4.0 * 1025 + 2.0 * self.nnz),
                   4.0 * B * (n + T * self.cfg.n_mels))
+        fn = L.lib().bsed_mel_scratch_floats
+        fn.restype = ctypes.c_long
+        scratch = torch.empty(fn(self._plan, L.c_int(B), L.c_int(n)), device=wav.device, dtype=torch.float32)
         L.call("bsed_mel_linear", self._plan, L.ptr(wav), L.c_int(B), L.c_int(n), L.ptr(mel), L.ptr(cmax),
-               L.ptr(sumsq), L.stream())
+               L.ptr(sumsq), L.ptr(scratch), L.stream())
         return mel, cmax, sumsq
 
     def stats(self, mel_lin):

@@ -48,9 +48,11 @@ int bsed_mel_plan_nnz(const void* plan);                    /* non-zeros of the 
 int bsed_mel_num_frames(const void* plan, int n_samples);   /* 1 + n_samples / hop */
 /* wav (B, n_samples) -> LINEAR mel amplitude (B, T, n_mels) == preprocess(audio).  Also emits the
  * per-clip max (B) and the per-(clip, band) sum over time of x^2 (B, n_mels), which the dB clamp and
- * the SNR noise need, so neither costs another pass over HBM. */
+ * the SNR noise need, so neither costs another pass over HBM.  scratch: bsed_mel_scratch_floats(plan, B, n_samples)
+ * floats (per-workgroup partial sums of squares, added in fixed order: the result is bitwise repeatable). */
+long bsed_mel_scratch_floats(const void* plan, int B, int n_samples);
 int bsed_mel_linear(const void* plan, const float* wav, int B, int n_samples, float* mel_lin,
-                    float* clip_max, float* bin_sumsq, void* stream);
+                    float* clip_max, float* bin_sumsq, float* scratch, void* stream);
 /* the same two statistics for features that arrive as linear mel (the reference's wav/<name>.npy files) */
 int bsed_mel_stats(const float* mel_lin, int B, int T, int n_mels, float* clip_max, float* bin_sumsq, void* stream);
 /* noisy = mel + N(0,1) * sqrt(mean_t(mel^2) * 10^(-snr/10))  (AugmentGaussianNoise.gaussian_noise).

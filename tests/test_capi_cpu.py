@@ -27,7 +27,7 @@ def test_error_convention_without_gpu():
     assert lib.bsed_abi_version() >= 1
     assert b"gfx950" in lib.bsed_build_info()
     # argument validation happens before any HIP call: NULL plan -> negative code + message
-    rc = lib.bsed_mel_linear(None, None, 1, 32000, None, None, None, None)
+    rc = lib.bsed_mel_linear(None, None, 1, 32000, None, None, None, None, None)
     assert rc < 0 and b"null" in lib.bsed_last_error()
 
 
