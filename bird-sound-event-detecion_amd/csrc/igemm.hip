@@ -532,6 +532,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
     sc = *reinterpret_cast<const float4*>(p.a_scale + cz0 + 4 * (tid & ((1 << P.lgc4) - 1)));
     sh = *reinterpret_cast<const float4*>(p.a_shift + cz0 + 4 * (tid & ((1 << P.lgc4) - 1)));
   }
+  // BatchNorm backward on load (bn_y set): d_y = A g + B y + (C - B mean) for the thread's own channel quad of dy
+  float4 cA = make_float4(1.f, 1.f, 1.f, 1.f), cB = make_float4(0.f, 0.f, 0.f, 0.f), cC = cB;
+  if (p.bn_y && n0 + 4 * (tid & (8 * P.ntw - 1)) < p.N) {
+    const int cn = n0 + 4 * (tid & (8 * P.ntw - 1));
+    cA = *reinterpret_cast<const float4*>(p.bn_coef + cn);
+    cB = *reinterpret_cast<const float4*>(p.bn_coef + p.N + cn);
+    const float4 c2 = *reinterpret_cast<const float4*>(p.bn_coef + 2 * p.N + cn);
+    const float4 mu = *reinterpret_cast<const float4*>(p.bn_mean + cn);
+    cC = make_float4(fmaf(-cB.x, mu.x, c2.x), fmaf(-cB.y, mu.y, c2.y), fmaf(-cB.z, mu.z, c2.z), fmaf(-cB.w, mu.w, c2.w));
+  }
 
   for (int tile0 = blockIdx.x; tile0 < P.ntiles; tile0 += gridDim.x) {
     int tile = tile0;
@@ -586,8 +596,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
         const int n4 = e & (n4n - 1), mm = e >> lgn4;
         const int gh_ = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e < d_total && gh_ < p.H && gw < p.W && n0 + 4 * n4 < p.N)
-          v[u] = *reinterpret_cast<const float4*>(dyb + ((size_t)gh_ * p.W + gw) * p.dy_pitch + n0 + 4 * n4);
+        if (e < d_total && gh_ < p.H && gw < p.W && n0 + 4 * n4 < p.N) {
+          const size_t o = ((size_t)nb * p.H * p.W + (size_t)gh_ * p.W + gw) * p.dy_pitch + n0 + 4 * n4;
+          v[u] = *reinterpret_cast<const float4*>(p.dy + o);
+          if (p.bn_y) {
+            // BatchNorm backward on load (NTHR is a multiple of n4n: the channel quad is the thread's own, cA/cB/cC)
+            const float4 yv = *reinterpret_cast<const float4*>(p.bn_y + o);
+            v[u].x = fmaf(cA.x, v[u].x, fmaf(cB.x, yv.x, cC.x)); v[u].y = fmaf(cA.y, v[u].y, fmaf(cB.y, yv.y, cC.y));
+            v[u].z = fmaf(cA.z, v[u].z, fmaf(cB.z, yv.z, cC.z)); v[u].w = fmaf(cA.w, v[u].w, fmaf(cB.w, yv.w, cC.w));
+            if (p.dy_out && blockIdx.z == 0) *reinterpret_cast<float4*>(p.dy_out + o) = v[u];
+          }
+        }
       }
 #pragma unroll
       for (int u = 0; u < UD; ++u) {
@@ -716,6 +735,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       sc = *reinterpret_cast<const float4*>(p.a_scale + cz0 + 4 * (tid & (c4n - 1)));
       sh = *reinterpret_cast<const float4*>(p.a_shift + cz0 + 4 * (tid & (c4n - 1)));
     }
+    // BatchNorm backward on load: d_y = A g + B y + (C - B mean); a thread's dy elements all sit in one channel quad
+    const bool bnb = p.bn_y != nullptr;
+    const bool dy_store = bnb && p.dy_out != nullptr && blockIdx.z == 0;   // one CIN chunk writes d_y out
+    float4 cA = make_float4(1.f, 1.f, 1.f, 1.f), cB = make_float4(0.f, 0.f, 0.f, 0.f), cC = cB;
+    if (bnb && n0 + 4 * (tid & (n4n - 1)) < p.N) {
+      const int cn = n0 + 4 * (tid & (n4n - 1));
+      cA = *reinterpret_cast<const float4*>(p.bn_coef + cn);
+      cB = *reinterpret_cast<const float4*>(p.bn_coef + p.N + cn);
+      const float4 c2 = *reinterpret_cast<const float4*>(p.bn_coef + 2 * p.N + cn);
+      const float4 mu = *reinterpret_cast<const float4*>(p.bn_mean + cn);
+      cC = make_float4(fmaf(-cB.x, mu.x, c2.x), fmaf(-cB.y, mu.y, c2.y), fmaf(-cB.z, mu.z, c2.z), fmaf(-cB.w, mu.w, c2.w));
+    }
     // tile-invariant element geometry: LDS offset, offset inside the image relative to the tile origin, patch row/col
     int xo[UX], xg[UX], xrc[UX], dyo[UD], dg[UD], drc[UD];
 #pragma unroll
@@ -744,9 +775,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int nb = t / p.tilesH;
       const int th0 = th_i * p.TH, tw0 = tw_i * p.TW;
       const float* inb = p.in + ((size_t)nb * p.H * p.W + (size_t)th0 * p.W + tw0) * p.in_pitch;
-      const float* dyb = p.dy + ((size_t)nb * p.H * p.W + (size_t)th0 * p.W + tw0) * p.dy_pitch;
+      const size_t dy_base = ((size_t)nb * p.H * p.W + (size_t)th0 * p.W + tw0) * p.dy_pitch;
+      const float* dyb = p.dy + dy_base;
       w3_f32x4 vx[UX], vd[UD];  // native vectors: arrays of HIP float4 structs end up in scratch
-      uint32_t okx = 0;
+      uint32_t okx = 0, okd = 0;
 #pragma unroll
       for (int u = 0; u < UX; ++u) {
         const int gh_ = th0 + (xrc[u] >> 16), gw = tw0 + (int)(short)(xrc[u] & 0xffff);
@@ -760,7 +792,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int u = 0; u < UD; ++u) {
         const int gh_ = th0 + (drc[u] >> 16), gw = tw0 + (drc[u] & 0xffff);
         vd[u] = w3_f32x4{0.f, 0.f, 0.f, 0.f};
-        if (gh_ < p.H && gw < p.W) vd[u] = *reinterpret_cast<const w3_f32x4*>(dyb + dg[u]);
+        if (gh_ < p.H && gw < p.W) {
+          vd[u] = *reinterpret_cast<const w3_f32x4*>(dyb + dg[u]);
+          okd |= 1u << u;
+        }
+      }
+      if (bnb) {
+        // y rides in a second register set; d_y is formed here and (one CIN chunk only) written out for the dgrad
+        w3_f32x4 vy[UD];
+#pragma unroll
+        for (int u = 0; u < UD; ++u) {
+          vy[u] = w3_f32x4{0.f, 0.f, 0.f, 0.f};
+          if ((okd >> u) & 1) vy[u] = *reinterpret_cast<const w3_f32x4*>(p.bn_y + dy_base + dg[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UD; ++u) {
+          if ((okd >> u) & 1) {
+            vd[u][0] = fmaf(cA.x, vd[u][0], fmaf(cB.x, vy[u][0], cC.x));
+            vd[u][1] = fmaf(cA.y, vd[u][1], fmaf(cB.y, vy[u][1], cC.y));
+            vd[u][2] = fmaf(cA.z, vd[u][2], fmaf(cB.z, vy[u][2], cC.z));
+            vd[u][3] = fmaf(cA.w, vd[u][3], fmaf(cB.w, vy[u][3], cC.w));
+            if (dy_store) *reinterpret_cast<w3_f32x4*>(p.dy_out + dy_base + dg[u]) = vd[u];
+          }
+        }
       }
       // (the buffer being written was last read before the previous barrier)
       const int bo = buf * buf_u16;
@@ -1125,6 +1179,18 @@ static int wgrad_prepare(const BsedWgradDesc* desc, WgradParams& P, size_t& smem
   BSED_CHECK_ARG(d.CIN % 4 == 0 && d.N % 4 == 0, "bsed_wgrad: CIN and N must be multiples of 4");
   BSED_CHECK_ARG(d.CINP % 32 == 0 && d.CINP >= d.CIN && d.NP % 32 == 0 && d.NP >= d.N, "bsed_wgrad: bad padding");
   BSED_CHECK_ARG(d.in_pitch >= d.CIN && d.in_pitch % 4 == 0 && d.dy_pitch >= d.N && d.dy_pitch % 4 == 0, "bsed_wgrad: bad pitch");
+  BSED_CHECK_ARG((d.bn_y == nullptr) == (d.bn_coef == nullptr) && (d.bn_y == nullptr) == (d.bn_mean == nullptr),
+                 "bsed_wgrad: bn_y, bn_coef and bn_mean come together (BatchNorm backward applied on load) or not at all");
+  BSED_CHECK_ARG(d.bn_y || !d.dy_out, "bsed_wgrad: dy_out only goes with bn_y");
+  BSED_CHECK_ARG(!d.bn_y || mode3, "bsed_wgrad: BatchNorm backward on load is built into the split-fp32 kernels (bsed_wgrad3) only");
+  BSED_CHECK_ARG(!d.dy_out || (d.dy_out != d.dy && d.dy_out != d.bn_y), "bsed_wgrad: dy_out must not alias dy or bn_y "
+                 "(other workgroups still read them)");
+  BSED_CHECK_ARG((d.bn_y == nullptr) == (d.bn_coef == nullptr) && (d.bn_y == nullptr) == (d.bn_mean == nullptr),
+                 "bsed_wgrad: bn_y, bn_coef and bn_mean come together (BatchNorm backward applied on load) or not at all");
+  BSED_CHECK_ARG(d.bn_y || !d.dy_out, "bsed_wgrad: dy_out only goes with bn_y");
+  BSED_CHECK_ARG(!d.bn_y || mode3, "bsed_wgrad: BatchNorm backward on load is built into the split-fp32 kernels (bsed_wgrad3) only");
+  BSED_CHECK_ARG(!d.dy_out || (d.dy_out != d.dy && d.dy_out != d.bn_y), "bsed_wgrad: dy_out must not alias dy or bn_y "
+                 "(other workgroups still read them)");
   d.tilesH = ceil_div(d.H, d.TH);
   d.tilesW = d.W / d.TW;
   P.PW = d.TW + 2 * d.hw;

@@ -33,11 +33,18 @@
 
 #define NFFT 2048
 #define NC 1024        // complex points
+#ifndef SM_WAVES
 #define SM_WAVES 4     // waves per workgroup (independent of each other until the final partial-sum hand-off)
+#endif
+#ifndef SM_FPW
 #define SM_FPW 8       // consecutive frames per wave
+#endif
+#ifndef SM_WPE
+#define SM_WPE 2       // waves per SIMD the register budget is held to
+#endif
 #define SM_PITCH 68    // exchange tile: row pitch in complex elements (16 rows x 64 + 4 pad)
 #define SM_TILE_FLOATS (2 * 16 * SM_PITCH)   // 8704 B per wave: exchange tile / Z image (1024 + 12 pad) / 1028 magnitudes
-#define SM_MAX_NIT 24  // float4 filterbank steps per lane (17 at 32 kHz, 16 at 22.05 kHz)
+#define SM_MAX_NIT 24  // float4 filterbank steps per lane (both bands)
 #define MEL_THREADS (64 * SM_WAVES)
 
 struct MelPlan {
@@ -57,7 +64,7 @@ struct MelPlan {
   float2* d_wl;      // [64]      W2048^lane
   float4* d_melw4;   // [nit][64] filterbank weights of lane's bands (lane, n_mels-1-lane), zero padded
   int4* d_melidx;    // [64]      {s0, n0, s1, n1}: 4-aligned first bin and float4 count of the two bands
-  int nit;
+  int nit, nit0, nit1;   // float4 steps: nit0 for the bands 'lane', nit1 for the bands 'n_mels-1-lane', nit = nit0 + nit1
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -145,11 +152,11 @@ __device__ __forceinline__ float quad_dpp(float x) {   // lane exchange inside a
 struct SmParams {
   const float* wav; int n_samples, hop, T, n_mels;
   const float* window; const float2* tw1; const float2* tw2; const float2* wl;
-  const float4* melw4; const int4* melidx; int nit;
+  const float4* melw4; const int4* melidx; int nit, nit0, nit1;
   float* mel_out; float* clip_max; float* sumsq_part;   // sumsq_part (B, gridDim.x, n_mels)
 };
 
-__global__ __launch_bounds__(MEL_THREADS, 2) void stft_mel_kernel(const SmParams P) {
+__global__ __launch_bounds__(MEL_THREADS, SM_WPE) void stft_mel_kernel(const SmParams P) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   float4* melw = reinterpret_cast<float4*>(smem_raw);                                     // [nit][64]
   c32* wins = reinterpret_cast<c32*>(smem_raw + (size_t)P.nit * 64 * sizeof(float4));     // [1024] window, (even, odd) pairs
@@ -166,6 +173,15 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void stft_mel_kernel(const SmParams
   }
   // per-lane constants (registers for the whole kernel).  Twiddle k = 4a + b is held as the two factors
   // W^(lane 4a) and W^(lane b) (6 complex numbers instead of 15 per pass; one extra multiply for a, b != 0)
+#if SM_WPE <= 2
+  // 256-register budget: all 15 + 15 twiddles of the two passes stay in registers
+  c32 tw1[15], tw2[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) {
+    const float2 a = P.tw1[k * 64 + lane], c = P.tw2[k * 64 + lane];
+    tw1[k] = c32{a.x, a.y}; tw2[k] = c32{c.x, c.y};
+  }
+#else
   c32 t1a[3], t1b[3], t2a[3], t2b[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -173,6 +189,7 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void stft_mel_kernel(const SmParams
     const float2 a2 = P.tw2[(4 * (i + 1) - 1) * 64 + lane], b2 = P.tw2[i * 64 + lane];
     t1a[i] = c32{a1.x, a1.y}; t1b[i] = c32{b1.x, b1.y}; t2a[i] = c32{a2.x, a2.y}; t2b[i] = c32{b2.x, b2.y};
   }
+#endif
   const float2 wl2 = P.wl[lane];
   const c32 wl = c32{wl2.x, wl2.y};
   const int4 mi = P.melidx[lane];
@@ -188,52 +205,70 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void stft_mel_kernel(const SmParams
   float run_max = 0.f, sq0 = 0.f, sq1 = 0.f;
   c32 v[16];
   int opq = 0;   // opaque zero, re-laundered per frame: keeps loop-invariant loads / products out of long-lived registers
-  auto load_frame = [&](int t) {
+  // interior frames: 16 loads of 8 bytes straight into the butterfly registers
+  auto interior = [&](int t) {
     const long s0 = (long)t * P.hop - NFFT / 2;
-    if (s0 >= 0 && s0 + NFFT <= P.n_samples) {
-      const float* src = w + s0 + 2 * lane;         // 4-byte aligned pairs: the hardware takes dwordx2 at dword alignment
+    return s0 >= 0 && s0 + NFFT <= (long)P.n_samples;
+  };
+  auto load_fast = [&](int t) {
+    const float* src = w + ((long)t * P.hop - NFFT / 2) + 2 * lane;   // 4-byte aligned pairs: dwordx2 at dword alignment
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        float2 x;
-        __builtin_memcpy(&x, src + 128 * j, sizeof(x));
-        v[j] = c32{x.x, x.y};
-      }
-    } else {   // librosa.stft(center=True, pad_mode='reflect') at the clip edges
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        float xs[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          long gi = s0 + 2 * (lane + 64 * j) + e;
-          if (gi < 0) gi = -gi;
-          if (gi >= P.n_samples) gi = 2L * (P.n_samples - 1) - gi;
-          gi = gi < 0 ? 0 : (gi >= P.n_samples ? P.n_samples - 1 : gi);
-          xs[e] = w[gi];
-        }
-        v[j] = c32{xs[0], xs[1]};
-      }
+    for (int j = 0; j < 16; ++j) {
+      float2 x;
+      __builtin_memcpy(&x, src + 128 * j, sizeof(x));
+      v[j] = c32{x.x, x.y};
     }
   };
-  if (t_begin < P.T) load_frame(t_begin);
+  // clip edges (librosa.stft(center=True, pad_mode='reflect')): the ~10 edge frames of a clip are staged through the
+  // wave's tile by a rolled loop (a second unrolled copy of the loads with mirrored indices cost 24 registers for the
+  // whole kernel), then picked up with the same register mapping
+  auto load_edge = [&](int t) {
+    const long s0 = (long)t * P.hop - NFFT / 2;
+#pragma unroll 1
+    for (int i = 0; i < NFFT / 64; ++i) {
+      long gi = s0 + 64 * i + lane;
+      if (gi < 0) gi = -gi;
+      if (gi >= P.n_samples) gi = 2L * (P.n_samples - 1) - gi;
+      gi = gi < 0 ? 0 : (gi >= P.n_samples ? P.n_samples - 1 : gi);
+      tile[64 * i + lane] = w[gi];
+    }
+    SM_FENCE();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = xb[lane + 64 * j];
+    SM_FENCE();
+  };
+  if (t_begin < P.T) {
+    if (interior(t_begin)) load_fast(t_begin); else load_edge(t_begin);
+  }
 #pragma unroll 1
   for (int f = 0; f < SM_FPW; ++f) {
     const int t = t_begin + f;
     if (t >= P.T) break;                             // wave-uniform
     asm volatile("" : "+v"(opq));
+#if SM_WPE <= 2
+    const c32 wlo = wl;                              // the eight W2048^k of the unpack are hoisted into registers too
+#else
 #pragma unroll
     for (int i = 0; i < 3; ++i) {                    // the nine twiddle products below are recomputed per frame, not hoisted
       asm volatile("" : "+v"(t1a[i].x), "+v"(t1a[i].y));
       asm volatile("" : "+v"(t2a[i].x), "+v"(t2a[i].y));
     }
+    c32 wlo = wl;                                    // likewise the eight W2048^k of the unpack
+    asm volatile("" : "+v"(wlo.x), "+v"(wlo.y));
+#endif
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] *= wins[opq + lane + 64 * j];   // window from LDS (read per frame: 32 registers saved)
     // ---- pass 1: 16-point DFT over j of z[l + 64 j], twiddle W1024^(l k1)
     dft16(v);
 #pragma unroll
     for (int k = 1; k < 16; ++k) {
+#if SM_WPE <= 2
+      v[k] = cmulw(v[k], tw1[k - 1]);
+#else
       const int a = k >> 2, bb = k & 3;
       const c32 tw = a == 0 ? t1b[bb - 1] : (bb == 0 ? t1a[a - 1] : cmulw(t1a[a - 1], t1b[bb - 1]));
       v[k] = cmulw(v[k], tw);
+#endif
     }
     SM_FENCE();
 #pragma unroll
@@ -246,9 +281,13 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void stft_mel_kernel(const SmParams
     dft16(v);
 #pragma unroll
     for (int k = 1; k < 16; ++k) {
+#if SM_WPE <= 2
+      v[k] = cmulw(v[k], tw2[k - 1]);
+#else
       const int a = k >> 2, bb = k & 3;
       const c32 tw = a == 0 ? t2b[bb - 1] : (bb == 0 ? t2a[a - 1] : cmulw(t2a[a - 1], t2b[bb - 1]));
       v[k] = cmulw(v[k], tw);
+#endif
     }
     // ---- pass 3: 4-point DFT across the quad's lanes; lane m ends with output q(m): k = g + 16 k2' + 256 q
 #pragma unroll
@@ -262,17 +301,23 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void stft_mel_kernel(const SmParams
     // ---- Z image: element k at k + 4 (k >> 8) (conflict-free 8-byte writes from the (g, q) lane pattern)
 #pragma unroll
     for (int k = 0; k < 16; ++k) xb[g + 16 * k + 260 * q] = v[k];
+    // The partner of bin k = lane + 64 i sits at 1024 - k + 4 ((1024 - k) >> 8) = 1036 - lane - 64 i - 4 (i >> 2) for every
+    // (lane, i) except lane 0 with i = 0 (partner Z[0]) and i = 4 (partner Z[768]): those two get a copy in the pad
+    // holes the formula points at, so that every pair address is one per-lane base plus an immediate
+    if (lane == 0) xb[1036] = v[0];
+    if (lane == 3) xb[776] = v[0];
     SM_FENCE();
     // ---- real-FFT unpack on pairs (k, 1024 - k), k = lane + 64 i: |E + t|, |E - t| are bins k and 1024 - k
     float mg_lo[8], mg_hi[8];
+    const c32* xb_rev = xb + (1036 - (64 * 7 + 4)) - lane;   // + positive immediates only
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int k = lane + 64 * i, kr = (NC - k) & (NC - 1);
-      const c32 zk = xb[k + 4 * (k >> 8)], zr = xb[kr + 4 * (kr >> 8)];
+      const c32 zk = xb[lane + 64 * i + 4 * (i >> 2)];
+      const c32 zr = xb_rev[(64 * 7 + 4) - (64 * i + 4 * (i >> 2))];
       const c32 e = c32{zk.x + zr.x, zk.y - zr.y};                 // 2 E
       const c32 o = c32{zk.y + zr.y, zr.x - zk.x};                 // 2 O = (Zk - conj Zr) / i
       const float a = 6.283185307179586477f * (float)(64 * i) / (float)NFFT;
-      const c32 wk = cmulw(wl, c32{__builtin_cosf(a), -__builtin_sinf(a)});   // W2048^k = W2048^lane * W32^i (constant folded)
+      const c32 wk = cmulw(wlo, c32{__builtin_cosf(a), -__builtin_sinf(a)});   // W2048^k = W2048^lane * W32^i (constant folded)
       const c32 tt = cmulw(o, wk);
       const c32 xp = e + tt, xm = e - tt;
       mg_lo[i] = 0.5f * __builtin_amdgcn_sqrtf(xp.x * xp.x + xp.y * xp.y);   // v_sqrt_f32 (1 ulp)
@@ -285,29 +330,38 @@ __global__ __launch_bounds__(MEL_THREADS, 2) void stft_mel_kernel(const SmParams
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       tile[lane + 64 * i] = mg_lo[i];
-      tile[NC - (lane + 64 * i)] = mg_hi[i];
+      (tile + (NC - 64 * 7) - lane)[64 * (7 - i)] = mg_hi[i];
     }
     if (lane == 0) tile[512] = mg512;
     if (lane >= 1 && lane <= 3) tile[NC + lane] = 0.f;
     SM_FENCE();
     // next frame's samples travel while the filterbank runs
-    if (f + 1 < SM_FPW && t + 1 < P.T) load_frame(t + 1);
+    const bool more = f + 1 < SM_FPW && t + 1 < P.T;
+    const bool fast = more && interior(t + 1);
+    if (fast) load_fast(t + 1);
     // ---- sparse filterbank: two bands per lane, float4 steps
+    // two uniform loops (zero-weight steps pad the shorter bands; their magnitude reads stay inside the tile, whose
+    // floats are all finite here: bins, zero pad, and older Z words)
     float acc0 = 0.f, acc1 = 0.f;
-    for (int it = 0; it < P.nit; ++it) {
-      const bool first = it < mi.y;
-      int idx = first ? mi.x + 4 * it : mi.z + 4 * (it - mi.y);
-      idx = idx > NC ? NC : idx;
-      const float4 mg = *reinterpret_cast<const float4*>(tile + idx);
-      const float4 ww = melw[it * 64 + lane];
-      const float d = fmaf(ww.x, mg.x, fmaf(ww.y, mg.y, fmaf(ww.z, mg.z, ww.w * mg.w)));
-      acc0 += first ? d : 0.f;
-      acc1 += first ? 0.f : d;
+    const float* m0 = tile + mi.x;
+    const float* m1 = tile + mi.z;
+    const float4* wq = melw + lane;
+    for (int it = 0; it < P.nit0; ++it) {
+      const float4 mg = *reinterpret_cast<const float4*>(m0 + 4 * it);
+      const float4 ww = wq[it * 64];
+      acc0 = fmaf(ww.x, mg.x, fmaf(ww.y, mg.y, fmaf(ww.z, mg.z, fmaf(ww.w, mg.w, acc0))));
+    }
+    wq += P.nit0 * 64;
+    for (int it = 0; it < P.nit1; ++it) {
+      const float4 mg = *reinterpret_cast<const float4*>(m1 + 4 * it);
+      const float4 ww = wq[it * 64];
+      acc1 = fmaf(ww.x, mg.x, fmaf(ww.y, mg.y, fmaf(ww.z, mg.z, fmaf(ww.w, mg.w, acc1))));
     }
     SM_FENCE();
     float* out = P.mel_out + ((size_t)b * P.T + t) * P.n_mels;
     if (has0) { out[band0] = acc0; run_max = fmaxf(run_max, acc0); sq0 = fmaf(acc0, acc0, sq0); }
     if (has1) { out[band1] = acc1; run_max = fmaxf(run_max, acc1); sq1 = fmaf(acc1, acc1, sq1); }
+    if (more && !fast) load_edge(t + 1);             // the tile is free again (magnitudes consumed)
   }
   const float wm = wave_max(run_max);
   if (lane == 0 && t_begin < P.T) atomicMax(reinterpret_cast<int*>(P.clip_max + b), __float_as_int(wm));
@@ -464,20 +518,27 @@ extern "C" int bsed_mel_plan_create(const BsedMelCfg* cfg, void** plan_out) {
     s4[mband] = count[mband] ? (start[mband] & ~3) : 0;
     n4[mband] = count[mband] ? (start[mband] + count[mband] - s4[mband] + 3) / 4 : 0;
   }
-  int nit = 1;
+  int nit0 = 0, nit1 = 0;
   for (int l = 0; l < 64; ++l) {
     const int b0 = l, b1 = nm - 1 - l;
     const bool h0 = b0 < nm && b0 <= b1, h1 = b1 >= 0 && b1 > b0;
     midx[l] = make_int4(h0 ? s4[b0] : 0, h0 ? n4[b0] : 0, h1 ? s4[b1] : 0, h1 ? n4[b1] : 0);
-    nit = std::max(nit, midx[l].y + midx[l].w);
+    nit0 = std::max(nit0, midx[l].y);
+    nit1 = std::max(nit1, midx[l].w);
   }
+  // a padded step reads 4 floats at most 4 * (steps - 1) + 3 past a band's first bin: keep that inside the tile
+  for (int l = 0; l < 64; ++l) {
+    BSED_CHECK_ARG(midx[l].x + 4 * nit0 <= SM_TILE_FLOATS && midx[l].z + 4 * nit1 <= SM_TILE_FLOATS,
+                   "bsed_mel_plan_create: filterbank steps leave the magnitude tile");
+  }
+  const int nit = nit0 + nit1;
   BSED_CHECK_ARG(nit <= SM_MAX_NIT, "bsed_mel_plan_create: filterbank needs %d float4 steps per lane (max %d)", nit, SM_MAX_NIT);
   std::vector<float4> w4((size_t)nit * 64, make_float4(0.f, 0.f, 0.f, 0.f));
   for (int l = 0; l < 64; ++l)
     for (int which = 0; which < 2; ++which) {
       const int band = which == 0 ? l : nm - 1 - l;
       const int sb = which == 0 ? midx[l].x : midx[l].z, nb = which == 0 ? midx[l].y : midx[l].w;
-      const int it0 = which == 0 ? 0 : midx[l].y;
+      const int it0 = which == 0 ? 0 : nit0;
       for (int i = 0; i < nb; ++i) {
         float e[4];
         for (int c = 0; c < 4; ++c) {
@@ -487,7 +548,7 @@ extern "C" int bsed_mel_plan_create(const BsedMelCfg* cfg, void** plan_out) {
         w4[(size_t)(it0 + i) * 64 + l] = make_float4(e[0], e[1], e[2], e[3]);
       }
     }
-  p->nit = nit;
+  p->nit = nit; p->nit0 = nit0; p->nit1 = nit1;
   BSED_HIP(hipMalloc(&p->d_tw1, tw1.size() * sizeof(float2)));
   BSED_HIP(hipMalloc(&p->d_tw2, tw2.size() * sizeof(float2)));
   BSED_HIP(hipMalloc(&p->d_wl, wl.size() * sizeof(float2)));
@@ -540,7 +601,7 @@ extern "C" int bsed_mel_linear(const void* plan, const float* wav, int B, int n_
   SmParams P;
   P.wav = wav; P.n_samples = n_samples; P.hop = p->cfg.hop; P.T = T; P.n_mels = p->cfg.n_mels;
   P.window = p->d_window; P.tw1 = p->d_tw1; P.tw2 = p->d_tw2; P.wl = p->d_wl;
-  P.melw4 = p->d_melw4; P.melidx = p->d_melidx; P.nit = p->nit;
+  P.melw4 = p->d_melw4; P.melidx = p->d_melidx; P.nit = p->nit; P.nit0 = p->nit0; P.nit1 = p->nit1;
   P.mel_out = mel_lin; P.clip_max = clip_max; P.sumsq_part = scratch;
   static BsedLdsOnce once;
   BSED_HIP(bsed_max_lds(once, (const void*)stft_mel_kernel));

@@ -416,12 +416,21 @@ class CRNN(_FlatModule):
             part, G = ops.conv0_wgrad(blk["inp"], g, B, Hh, Ww, co, y=y, coef=coef, mean=blk["mean"])
             ops.reduce_partials(part, G, 9, 1, co, 1, co, cw.grad, 1, 9, 9)
             return None
-        # (4) BatchNorm backward -> d_y in place
-        ops.bn_bwd(st2, co, float(B * Hh * Ww), bn.weight, blk["mean"], blk["invstd"], bn.weight.grad,
-                   bn.bias.grad, g, y)
-        dy = g
         taps, wsrc, s_tap = self._conv_taps(cw, Ww)
-        part, G, KP, NP = ops.wgrad(blk["inp"], dy, B, Hh, Ww, cin, co, taps=taps)
+        if self.conv_mode == "bf16x3":
+            # (4) BatchNorm backward applied on load inside the weight-gradient kernel (d_y = A g + B (y - mean) + C),
+            # which also writes d_y once for the data gradient: the separate apply pass over g and y is gone
+            coef = ops.bn_bwd(st2, co, float(B * Hh * Ww), bn.weight, blk["mean"], blk["invstd"], bn.weight.grad,
+                              bn.bias.grad, g, y, apply=False)
+            dy = torch.empty_like(g) if need_dgrad else None
+            part, G, KP, NP = ops.wgrad(blk["inp"], g, B, Hh, Ww, cin, co, taps=taps, bn_y=y, bn_coef=coef,
+                                        bn_mean=blk["mean"], dy_out=dy)
+        else:
+            # (4) BatchNorm backward -> d_y in place
+            ops.bn_bwd(st2, co, float(B * Hh * Ww), bn.weight, blk["mean"], blk["invstd"], bn.weight.grad,
+                       bn.bias.grad, g, y)
+            dy = g
+            part, G, KP, NP = ops.wgrad(blk["inp"], dy, B, Hh, Ww, cin, co, taps=taps)
         ops.reduce_partials(part, G, len(taps), KP, NP, cin, co, cw.grad, s_tap, 9, cin * 9,
                             dst_offset=0 if Ww > 1 else 1)
         if not need_dgrad:

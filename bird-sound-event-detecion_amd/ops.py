@@ -27,7 +27,8 @@ class WgradDesc(ctypes.Structure):
     _fields_ = ([(n, _fp) for n in ("in_", "dy", "part", "a_scale", "a_shift")]
                 + [(n, _i) for n in ("in_pitch", "dy_pitch", "NB", "H", "W", "CIN", "CINP", "N", "NP", "G", "TH", "TW",
                                      "tilesH", "tilesW", "hh", "hw", "ntaps")]
-                + [("dh", _i * 9), ("dw", _i * 9)])
+                + [("dh", _i * 9), ("dw", _i * 9)]
+                + [(n, _fp) for n in ("bn_y", "bn_coef", "bn_mean", "dy_out")])
 
 
 class HeadBwdDesc(ctypes.Structure):
@@ -276,8 +277,10 @@ WGRAD_MODE = {"mode": None}  # None = follow BSED_CONV_MODE; "fp32" / "bf16x3" f
 
 
 def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=None, a_scale=None, a_shift=None,
-          in_offset=0, dy_offset=0, mode=None):
-    """Partial slabs of dW; returns (part, G, CINP, NP).  mode "bf16x3" = split-fp32 operands on the bf16 cores."""
+          in_offset=0, dy_offset=0, mode=None, bn_y=None, bn_coef=None, bn_mean=None, dy_out=None):
+    """Partial slabs of dW; returns (part, G, CINP, NP).  mode "bf16x3" = split-fp32 operands on the bf16 cores.
+    bn_y / bn_coef / bn_mean: `dy` is dL/d(BatchNorm output) and BatchNorm's backward is applied on load (bf16x3 only);
+    dy_out then receives d_y for the data-gradient convolution."""
     import os
     mode = mode or WGRAD_MODE["mode"] or os.environ.get("BSED_CONV_MODE", "bf16x3")
     sfx = "3" if mode == "bf16x3" else ""
@@ -287,6 +290,7 @@ def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=Non
     ntiles = NB * ((H + TH - 1) // TH) * (W // TW)
     d.in_ = _dp(inp, in_offset); d.dy = _dp(dy, dy_offset)
     d.a_scale = _p(a_scale); d.a_shift = _p(a_shift)
+    d.bn_y, d.bn_coef, d.bn_mean, d.dy_out = _p(bn_y), _p(bn_coef), _p(bn_mean), _p(dy_out)
     d.in_pitch = CIN if in_pitch is None else in_pitch
     d.dy_pitch = N if dy_pitch is None else dy_pitch
     d.NB, d.H, d.W, d.CIN, d.CINP, d.N, d.NP, d.G = NB, H, W, CIN, CINP, N, NP, 0
@@ -309,8 +313,10 @@ def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=Non
         kname = f"wgrad3_kernel<{var // 16}, {var % 16}, {'true' if bs else 'false'}>"
     else:
         kname = f"wgrad_kernel<{var // 16}, {var % 16}>"
+    # algorithmic bytes: the input and dy once; with the fused BatchNorm backward also y (read) and d_y (written)
+    nbytes = 4.0 * NB * H * W * (CIN + N * (1 + (1 if bn_y is not None else 0) + (1 if dy_out is not None else 0)))
     _launch((kname, len(taps), CIN, N, H, W),
-            2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call(f"bsed_wgrad{sfx}", ctypes.byref(d), L.stream()))
+            2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call(f"bsed_wgrad{sfx}", ctypes.byref(d), L.stream()), nbytes)
     return part, G, CINP, NP
 
 

@@ -138,6 +138,14 @@ typedef struct BsedWgradDesc {
   int NB, H, W, CIN, CINP, N, NP, G;
   int TH, TW, tilesH, tilesW, hh, hw;
   int ntaps, dh[9], dw[9];
+  /* BatchNorm backward applied on load (bsed_wgrad3 only; all four NULL = plain dy).  With bn_y set, `dy` holds
+   * g = dL/d(BatchNorm output) and the contraction runs on d_y = A g + B (bn_y - mean) + C, bn_coef = (3,N) [A|B|C] from
+   * bsed_bn_bwd, bn_y / dy_out laid out like dy.  dy_out (optional) receives d_y, written once per element, for the
+   * data-gradient convolution that follows: the separate apply pass over g and y (3 tensor passes) is gone. */
+  const float* bn_y;
+  const float* bn_coef;
+  const float* bn_mean;
+  float* dy_out;
 } BsedWgradDesc;
 
 int bsed_wgrad(const BsedWgradDesc* desc /*host*/, void* stream);

@@ -3,7 +3,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from bsed_amd.features import MelConfig, MelFrontEnd  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
