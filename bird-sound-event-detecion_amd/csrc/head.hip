@@ -307,6 +307,71 @@ extern "C" int bsed_binarize_median(const float* strong, float* out, int B, int 
   return BSED_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Contiguous-region decode of the binarised, median-filtered predictions (reference ManyHotEncoder.decode_strong,
+// src/utilities/ManyHotEncoder.py:148-164, on dcase_util's find_contiguous_regions: a region starts where the column
+// turns on (or at frame 0 if it starts on) and ends where it turns off (or at T)), followed by the frame -> second
+// conversion of get_predictions (src/evaluation_measures.py:205-209: frame * pooling_time_ratio / (sr / hop), clipped
+// to [0, max_len_seconds], float64 as pandas does it).  One thread per (clip, class) column; two passes (count, then
+// write at the exclusive prefix of the counts) so that the event list comes out in the reference's order: clip, then
+// class, then time.
+// ---------------------------------------------------------------------------------------------
+__global__ void decode_count_kernel(const float* __restrict__ mask, int B, int T, int C, int* __restrict__ counts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
+  const float* col = mask + (size_t)b * T * C + c;
+  int n = 0;
+  bool prev = false;
+  for (int t = 0; t < T; ++t) {
+    const bool on = col[(size_t)t * C] != 0.f;
+    n += (on && !prev) ? 1 : 0;
+    prev = on;
+  }
+  counts[i] = n;
+}
+
+__global__ void decode_write_kernel(const float* __restrict__ mask, const int* __restrict__ offsets, int B, int T, int C,
+                                    double scale, double max_len, int* __restrict__ ev_clip, int* __restrict__ ev_class,
+                                    int* __restrict__ ev_frames, double* __restrict__ ev_seconds) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
+  const float* col = mask + (size_t)b * T * C + c;
+  int k = offsets[i];
+  bool prev = false;
+  int onset = 0;
+  for (int t = 0; t <= T; ++t) {
+    const bool on = t < T && col[(size_t)t * C] != 0.f;
+    if (on && !prev) onset = t;
+    if (!on && prev) {
+      ev_clip[k] = b; ev_class[k] = c;
+      ev_frames[2 * k] = onset; ev_frames[2 * k + 1] = t;
+      ev_seconds[2 * k] = fmin(fmax((double)onset * scale, 0.0), max_len);
+      ev_seconds[2 * k + 1] = fmin(fmax((double)t * scale, 0.0), max_len);
+      ++k;
+    }
+    prev = on;
+  }
+}
+
+extern "C" int bsed_decode_count(const float* mask, int B, int T, int C, int* counts, void* stream) {
+  BSED_CHECK_ARG(mask && counts && B > 0 && T > 0 && C > 0, "bsed_decode_count: bad argument");
+  hipLaunchKernelGGL(decode_count_kernel, dim3((B * C + 127) / 128), dim3(128), 0, (hipStream_t)stream, mask, B, T, C, counts);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_decode_write(const float* mask, const int* offsets, int B, int T, int C, double scale, double max_len,
+                                 int* ev_clip, int* ev_class, int* ev_frames, double* ev_seconds, void* stream) {
+  BSED_CHECK_ARG(mask && offsets && ev_clip && ev_class && ev_frames && ev_seconds && B > 0 && T > 0 && C > 0,
+                 "bsed_decode_write: bad argument");
+  hipLaunchKernelGGL(decode_write_kernel, dim3((B * C + 127) / 128), dim3(128), 0, (hipStream_t)stream, mask, offsets, B, T,
+                     C, scale, max_len, ev_clip, ev_class, ev_frames, ev_seconds);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
 // time splits per clip: enough workgroups for ~4 per CU, whole 32-frame chunks each
 extern "C" int bsed_head_splits(int B, int T) {
   const int chunks = (T + HD_FR - 1) / HD_FR;

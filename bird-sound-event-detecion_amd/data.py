@@ -5,6 +5,9 @@
   FeatureDataset         <- ENA_Dataset / SYN_Dataset, reference src/data/dataload.py:17-82,127-196
                             (item = ((features, target), path); the per-item CPU transforms of the reference --
                              noise, amplitude_to_db, pad/trunc -- are NOT applied here)
+  PseudoWeakDataset      <- ENA_Dataset_unlabeled, reference src/data/dataload.py:84-126: unlabeled in-domain clips whose
+                            weak targets come from ONE pseudo-label TSV (``filename<TAB>event_labels``, the shipped
+                            src/unlabel_in_domain_pseudo_weak*.tsv) instead of per-clip annotation files
   GpuCollate             batches items and runs the reference's transform chain (get_transforms,
                             src/data/Transforms.py:304-322) for the WHOLE batch on the GPU (csrc/mel.hip kernels):
                             returns ((x, x_noisy), target), paths like the reference's DataLoader batches.
@@ -45,6 +48,57 @@ class FeatureDataset(torch.utils.data.Dataset):
         if self.transform is not None:
             sample = self.transform(sample)
         return sample, path
+
+
+class PseudoWeakDataset(torch.utils.data.Dataset):
+    """Unlabeled in-domain clips with pseudo weak labels (reference ``ENA_Dataset_unlabeled``, dataload.py:84-126).
+
+    item = ((features, target), path) with ``target = encod_func(event_labels of the rows whose filename == path)`` --
+    a pandas Series of comma-separated label strings, which is what ``ManyHotEncoder.encode_weak`` takes; a clip without
+    a row gets the all-zero vector, as in the reference.  The reference hard-codes the TSV's location and re-reads it for
+    every item; here it is an argument and read once.  ``match``: "path" compares the full feature path with the TSV's
+    ``filename`` column exactly like the reference; "basename" compares file names only (for a data set that was moved
+    after the TSV was written -- the shipped files carry /home/fumchin/... paths)."""
+
+    def __init__(self, preprocess_dir, encod_func, transform=None, pseudo_label_tsv=None, match="path", compute_log=False):
+        import pandas as pd
+        if pseudo_label_tsv is None:
+            raise ValueError("PseudoWeakDataset needs pseudo_label_tsv (the reference hard-codes "
+                             "src/unlabel_in_domain_pseudo_weak_resNet.tsv)")
+        if match not in ("path", "basename"):
+            raise ValueError("match must be 'path' or 'basename'")
+        self.preprocess_dir = preprocess_dir
+        self.annotation_dir = pseudo_label_tsv              # (the reference keeps the TSV path under this name)
+        self.feature_dir = os.path.join(preprocess_dir, "wav")
+        self.feature_file_list = sorted(glob.glob(os.path.join(self.feature_dir, "*.npy")))
+        self.encod_func, self.transform, self.match = encod_func, transform, match
+        df = pd.read_csv(pseudo_label_tsv, sep="\t")
+        if not {"filename", "event_labels"}.issubset(df.columns):
+            raise ValueError(f"{pseudo_label_tsv}: expected the columns filename and event_labels, got {list(df.columns)}")
+        self._key = df["filename"] if match == "path" else df["filename"].map(os.path.basename)
+        self._df = df
+
+    def __len__(self):
+        return len(self.feature_file_list)
+
+    def labels_of(self, path):
+        key = path if self.match == "path" else os.path.basename(path)
+        return self._df[self._key == key]["event_labels"]
+
+    def __getitem__(self, index):
+        path = self.feature_file_list[index]
+        features = np.load(path)
+        target = self.encod_func(self.labels_of(path))
+        sample = (features, target)
+        if self.transform is not None:
+            sample = self.transform(sample)
+        return sample, path
+
+
+# the reference's class names (src/data/dataload.py), for import-swap drivers
+ENA_Dataset = FeatureDataset
+SYN_Dataset = FeatureDataset
+ENA_Dataset_unlabeled = PseudoWeakDataset
 
 
 class GpuCollate:

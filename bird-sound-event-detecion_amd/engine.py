@@ -10,9 +10,11 @@
 
 Everything between the waveform batch and the updated parameters runs in HIP kernels on the current
 stream; the host only sequences launches (no ``.item()`` / device syncs inside the step, unlike the
-reference's >= 6 syncs per iteration).  Data parallelism: one process per GPU, the two flat gradient
-arenas are all-reduced with RCCL (``torch.distributed``, backend "nccl") and the 1/world factor is folded
-into the optimizer kernel.
+reference's >= 6 syncs per iteration).  Data parallelism: one process per GPU; the gradients of CRNN, Predictor
+and discriminator live in ONE flat arena (``parallel.GradArena``) whose all-reduce (RCCL through
+``torch.distributed``, backend "nccl") is started from inside the last backward pass, as soon as every gradient
+but the first two CNN blocks' has been enqueued, and overlaps the rest of it; the 1/world factor is folded into
+the optimizer kernel.
 """
 import numpy as np
 import torch
@@ -76,8 +78,22 @@ def update_ema_variables(model, ema_model, alpha, global_step):
 
 
 # ----------------------------------------------------------------------------- optimizers on flat arenas
+def _ref_params(modules):
+    """[(module, name, offset, numel, shape)] in the reference optimizer's parameter order
+    (``list(crnn.parameters()) + list(predictor.parameters())``, src/main_baseline.py:865)"""
+    out = []
+    for m in modules:
+        names = m.reference_param_names() if hasattr(m, "reference_param_names") else [n for n, _ in m.named_parameters()]
+        for n in names:
+            p = m.P(n)
+            out.append((m, n, m._poff[n], p.numel(), tuple(p.shape)))
+    return out
+
+
 class FlatAdam:
-    """torch.optim.Adam(lr, betas, eps, weight_decay) over the flat arenas of several modules."""
+    """torch.optim.Adam(lr, betas, eps, weight_decay) over the flat arenas of several modules.  ``state_dict`` /
+    ``load_state_dict`` speak torch.optim.Adam's format (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` in
+    the reference's parameter order, CPU tensors), so the ``optimizer`` entry of a checkpoint loads on either side."""
 
     def __init__(self, modules, lr=0.001, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.modules = list(modules)
@@ -97,17 +113,48 @@ class FlatAdam:
                           self.weight_decay, grad_scale)
 
     def state_dict(self):
-        return {"step": self.step_count, "lr": self.lr, "m": [t.clone() for t in self.m],
-                "v": [t.clone() for t in self.v]}
+        state = {}
+        for i, (mod, _, off, n, shape) in enumerate(_ref_params(self.modules)):
+            k = self.modules.index(mod)
+            if self.step_count > 0:
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.m[k][off:off + n].view(shape).detach().cpu().clone(),
+                            "exp_avg_sq": self.v[k][off:off + n].view(shape).detach().cpu().clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "params": list(range(len(_ref_params(self.modules))))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.step_count, self.lr = sd["step"], sd["lr"]
-        for dst, src in zip(self.m + self.v, sd["m"] + sd["v"]):
-            dst.copy_(src)
+        if "param_groups" not in sd:          # round-1 files: {"step", "lr", "m", "v"}
+            self.step_count, self.lr = sd["step"], sd["lr"]
+            for dst, src in zip(self.m + self.v, sd["m"] + sd["v"]):
+                dst.copy_(src)
+            return
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
+        self.weight_decay = g.get("weight_decay", 0.0)
+        params = _ref_params(self.modules)
+        if len(g["params"]) != len(params):
+            raise L.BsedError(f"optimizer state has {len(g['params'])} parameters, the modules have {len(params)}")
+        steps = set()
+        for idx, (mod, _, off, n, shape) in zip(g["params"], params):
+            st = sd["state"].get(idx)
+            k = self.modules.index(mod)
+            if st is None:
+                self.m[k][off:off + n].zero_(); self.v[k][off:off + n].zero_()
+                continue
+            self.m[k][off:off + n].copy_(torch.as_tensor(st["exp_avg"]).reshape(-1))
+            self.v[k][off:off + n].copy_(torch.as_tensor(st["exp_avg_sq"]).reshape(-1))
+            steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise L.BsedError(f"per-parameter step counts differ ({sorted(steps)}): one flat Adam step cannot hold them")
+        self.step_count = steps.pop() if steps else 0
 
 
 class FlatSGD:
-    """torch.optim.SGD(lr, momentum, nesterov=True, weight_decay) (reference main_scmt_ada_weak.py:854-866)."""
+    """torch.optim.SGD(lr, momentum, nesterov=True, weight_decay) (reference main_scmt_ada_weak.py:854-866);
+    state_dict in torch.optim.SGD's format (``momentum_buffer`` per parameter)."""
 
     def __init__(self, modules, lr=0.001, momentum=0.9, weight_decay=1e-4, nesterov=True):
         self.modules = list(modules)
@@ -124,6 +171,34 @@ class FlatSGD:
             ops.sgd_step(mod.flat, mod.flat_grad, buf, self.lr, self.momentum, self.weight_decay,
                          self.step_count == 0, self.nesterov, grad_scale)
         self.step_count += 1
+
+    def state_dict(self):
+        state = {}
+        params = _ref_params(self.modules)
+        for i, (mod, _, off, n, shape) in enumerate(params):
+            k = self.modules.index(mod)
+            state[i] = {"momentum_buffer": (self.buf[k][off:off + n].view(shape).detach().cpu().clone()
+                                            if self.step_count > 0 else None)}
+        group = {"lr": self.lr, "momentum": self.momentum, "dampening": 0, "weight_decay": self.weight_decay,
+                 "nesterov": self.nesterov, "maximize": False, "foreach": None, "differentiable": False, "fused": None,
+                 "params": list(range(len(params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        self.lr, self.momentum, self.weight_decay = g["lr"], g["momentum"], g.get("weight_decay", 0.0)
+        self.nesterov = g.get("nesterov", True)
+        params = _ref_params(self.modules)
+        seen = False
+        for idx, (mod, _, off, n, shape) in zip(g["params"], params):
+            st = sd["state"].get(idx) or {}
+            k = self.modules.index(mod)
+            mb = st.get("momentum_buffer")
+            if mb is None:
+                self.buf[k][off:off + n].zero_()
+            else:
+                self.buf[k][off:off + n].copy_(torch.as_tensor(mb).reshape(-1)); seen = True
+        self.step_count = 1 if seen else 0      # only "first step or not" matters to the kernel
 
 
 # ----------------------------------------------------------------------------- the train step
@@ -152,16 +227,23 @@ class SEDTrainer:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
             self.rank = torch.distributed.get_rank(process_group)
+        # one gradient arena for everything this rank differentiates: [CRNN (first blocks lead) | Predictor | D]
+        disc = domain_loss.domain_discriminator if domain_loss is not None else None
+        self.arena = parallel.GradArena([crnn, predictor, disc], tail_floats=crnn.tail_grad_floats(),
+                                        group=process_group)
 
     def broadcast_parameters(self, src=0):
         """identical initial weights / statistics on every rank"""
         if self.world == 1:
             return
-        for m in (self.crnn, self.predictor, self.ema_crnn, self.ema_predictor):
+        disc = self.domain_loss.domain_discriminator if self.domain_loss is not None else None
+        for m in (self.crnn, self.predictor, self.ema_crnn, self.ema_predictor, disc):
             if m is None:
                 continue
             bufs = [m.flat] + ([m.flat_buf] if getattr(m, "flat_buf", None) is not None else [])
             parallel.broadcast_flat(bufs, src, self.pg)
+            if getattr(m, "nbt", None) is not None:
+                parallel.broadcast_flat([m.nbt], src, self.pg)
 
     def _features(self, wav, noisy=False):
         T = self.frontend.num_frames(wav.shape[1])
@@ -169,12 +251,8 @@ class SEDTrainer:
                                        seed=parallel.rank_seed(self.seed, self.global_step, self.rank))
 
     def _all_reduce_grads(self):
-        if self.world == 1:
-            return
-        bufs = [self.crnn.flat_grad, self.predictor.flat_grad]
-        if self.domain_loss is not None:
-            bufs.append(self.domain_loss.domain_discriminator.flat_grad)
-        parallel.all_reduce_flat(bufs, self.pg)
+        """wait for the early segment's all-reduce (started inside the last backward pass), exchange the tail"""
+        self.arena.finish()
 
     def train_step(self, syn_x, syn_y, real_x=None, real_y_weak=None, real_x_ema=None, consistency_cost=None,
                    from_wave=False):
@@ -195,11 +273,10 @@ class SEDTrainer:
                     real_x = self._features(real_x)
         step_seed = parallel.rank_seed(self.seed, self.global_step, self.rank)
         crnn.train(); pred.train()
-        self.optimizer.zero_grad()
+        self.arena.zero_()
         adv = self.domain_loss is not None and real_x is not None
         if adv:
             self.domain_loss.domain_discriminator.train()
-            self.optimizer_d.zero_grad()
         out = {}
         B, Tp, C = syn_y.shape
         # ---- student on the synthetic batch: strong + weak BCE
@@ -218,7 +295,9 @@ class SEDTrainer:
             out["domain"] = self.domain_loss(None, enc_s, None, enc_r)
             dfs, dft = self.domain_loss.backward_features()
             ops.axpy(dx, dfs)
-        crnn.run_backward(ctx_s, dx)
+        # the gradient exchange starts inside the LAST backward pass of the step
+        last_is_syn = real_x is None or not (mt or dft is not None)
+        crnn.run_backward(ctx_s, dx, on_early_grads=self.arena.begin_early if last_is_syn else None)
         del ctx_s
         # ---- student on the real batch (+ EMA teacher on its noisy twin)
         if real_x is not None:
@@ -237,11 +316,11 @@ class SEDTrainer:
                                            ema_weak=weak_e, w_cons_s=w, w_cons_w=w)
                 if dft is not None:
                     ops.axpy(dx, dft)
-                crnn.run_backward(ctx_r, dx)
+                crnn.run_backward(ctx_r, dx, on_early_grads=self.arena.begin_early)
                 out["real"] = lp
                 del ctx_r
             elif dft is not None:
-                crnn.run_backward(ctx_r, dft.contiguous())
+                crnn.run_backward(ctx_r, dft.contiguous(), on_early_grads=self.arena.begin_early)
                 del ctx_r
         # ---- data-parallel gradient exchange + update
         self._all_reduce_grads()
@@ -277,7 +356,7 @@ class SEDTrainer:
         sp = torch.as_tensor([int(v / pooling_time_ratio) for v in shift_frames], dtype=torch.int32, device=dev)
         step_seed = parallel.rank_seed(self.seed, self.global_step, self.rank)
         crnn.train(); pred.train(); ema_c.train(); ema_p.train()
-        self.optimizer.zero_grad()
+        self.arena.zero_()
         syn_x, real_x, real_x_ema = syn_x.contiguous(), real_x.contiguous(), real_x_ema.contiguous()
         syn_y = syn_y.contiguous()
         y_weak_syn = syn_y.max(-2)[0].contiguous()
@@ -333,7 +412,7 @@ class SEDTrainer:
         # synthetic, frequency shift: strong + weak BCE vs the unshifted targets
         enc, sv, ctx = fwd(ops.roll(syn_x, B, T, F, sw=sf), 5)
         dx, out["syn_fshift"] = pred.run_backward(enc, sv, y_strong=syn_y, y_weak=y_weak_syn)
-        crnn.run_backward(ctx, dx)
+        crnn.run_backward(ctx, dx, on_early_grads=self.arena.begin_early)
         del ctx
         self._all_reduce_grads()
         self.optimizer.step(grad_scale=1.0 / self.world)

@@ -1,23 +1,30 @@
 """Inference / event decoding -- host-side mirror of the reference's ``get_predictions``.
 
-  get_predictions   <- reference src/evaluation_measures.py:123-283: eval-mode forward (HIP), threshold,
-                       (median_window, 1) median filter, ``decoder`` (ManyHotEncoder.decode_strong), frames ->
-                       seconds with ``pooling_time_ratio / (sr / hop)``, clip to [0, max_len_seconds];
-                       optional embedding dump ``<saved_feature_dir>/<i>.npy`` (what save_features.py is for).
-Metric values (sed_eval / psds_eval) stay external: only the event lists are produced here.
-The post-processing runs on the host exactly as in the reference (pandas / scipy); moving it to the GPU is
-SURVEY.md section 8(f) rank 3.
+  get_predictions   <- reference src/evaluation_measures.py:123-283: eval-mode forward, threshold, (median_window, 1)
+                       median filter, ``decoder`` (ManyHotEncoder.decode_strong: contiguous regions), frames -> seconds
+                       with ``pooling_time_ratio / (sr / hop)`` clipped to [0, max_len_seconds]; ground-truth frame
+                       from ``annotation/<name>.txt`` next to the features, duration frame (10 s per clip); optional
+                       embedding dump ``<saved_feature_dir>/<i>.npy`` (what save_features.py is for).
+                       Returns ``(predictions, groundtruth_df, duration_df)`` like the reference (:283).
+Everything per frame runs on the GPU for the whole batch: forward (HIP), threshold + median filter
+(``bsed_binarize_median``), contiguous-region decode and the seconds conversion (``bsed_decode_count`` /
+``bsed_decode_write``).  Only the event list (a few rows per clip) travels to the host, where the DataFrames are
+assembled without a per-clip Python loop.  Metric values (sed_eval / psds_eval) stay external.
 """
+import ctypes
 import os
 
 import numpy as np
-import scipy.ndimage
 import torch
+
+from . import _lib as L
 
 
 def post_process(pred_strong, decoder, threshold=0.5, median_window=1, pooling_time_ratio=1, sr=32000,
                  hop_size=255, max_len_seconds=10.0):
-    """(T', C) probabilities -> list of [event_label, onset_s, offset_s]"""
+    """Host restatement for ONE clip ((T', C) probabilities -> list of [event_label, onset_s, offset_s]); kept for
+    callers that hand in a custom ``decoder`` function (the GPU decode needs the label list of a ManyHotEncoder)."""
+    import scipy.ndimage
     binar = (np.asarray(pred_strong) > threshold).astype(np.float64)
     binar = scipy.ndimage.median_filter(binar, (median_window, 1))
     scale = pooling_time_ratio / (sr / hop_size)
@@ -27,9 +34,7 @@ def post_process(pred_strong, decoder, threshold=0.5, median_window=1, pooling_t
 
 def binarize_median_gpu(pred_strong, threshold=0.5, median_window=1):
     """(B,T',C) GPU probabilities -> (B,T',C) 0/1 mask: threshold + scipy-compatible median filter, one HIP kernel
-    for the whole batch (SURVEY.md 8f rank 3) instead of a per-clip scipy call"""
-    import ctypes
-    from . import _lib as L
+    for the whole batch instead of a per-clip scipy call"""
     x = pred_strong.contiguous()
     B, T, C = x.shape
     out = torch.empty_like(x)
@@ -38,13 +43,46 @@ def binarize_median_gpu(pred_strong, threshold=0.5, median_window=1):
     return out
 
 
+def decode_regions_gpu(mask, scale, max_len_seconds):
+    """(B,T',C) 0/1 GPU mask -> (clip (E,), class (E,), frames (E,2), seconds (E,2)) numpy arrays, ordered by clip,
+    class, time: ManyHotEncoder.decode_strong for every clip of the batch plus the frames -> seconds conversion, in
+    two HIP launches (count, write at the exclusive prefix of the counts)."""
+    mask = mask.contiguous()
+    B, T, C = mask.shape
+    counts = torch.empty(B * C, device=mask.device, dtype=torch.int32)
+    L.call("bsed_decode_count", L.ptr(mask), L.c_int(B), L.c_int(T), L.c_int(C), L.ptr(counts, torch.int32), L.stream())
+    csum = torch.cumsum(counts, 0, dtype=torch.int32)
+    offsets = (csum - counts).contiguous()
+    E = int(csum[-1])                                   # the one host sync of the decode: the list length
+    ev_clip = torch.empty(max(E, 1), device=mask.device, dtype=torch.int32)
+    ev_class = torch.empty(max(E, 1), device=mask.device, dtype=torch.int32)
+    ev_frames = torch.empty((max(E, 1), 2), device=mask.device, dtype=torch.int32)
+    ev_seconds = torch.empty((max(E, 1), 2), device=mask.device, dtype=torch.float64)
+    if E:
+        L.call("bsed_decode_write", L.ptr(mask), L.ptr(offsets, torch.int32), L.c_int(B), L.c_int(T), L.c_int(C),
+               ctypes.c_double(scale), ctypes.c_double(max_len_seconds), L.ptr(ev_clip, torch.int32),
+               L.ptr(ev_class, torch.int32), L.ptr(ev_frames, torch.int32), L.ptr(ev_seconds, torch.float64), L.stream())
+    return (ev_clip[:E].cpu().numpy(), ev_class[:E].cpu().numpy(), ev_frames[:E].cpu().numpy(),
+            ev_seconds[:E].cpu().numpy())
+
+
+def _decoder_labels(decoder):
+    """label list of the ManyHotEncoder whose bound ``decode_strong`` was passed as ``decoder`` (the reference's call
+    sites pass ``many_hot_encoder.decode_strong``, src/main_baseline.py:1010-1032), or None for any other callable"""
+    owner = getattr(decoder, "__self__", None)
+    if owner is not None and getattr(decoder, "__name__", "") == "decode_strong" and hasattr(owner, "labels"):
+        return list(owner.labels)
+    return None
+
+
 def get_predictions(model, dataloader, decoder, pooling_time_ratio=1, thresholds=(0.5,), median_window=1,
                     save_predictions=None, del_model=False, learned_post=False, predictor=None, fpn=False,
                     saved_feature_dir=None, sr=32000, hop_size=255, max_len_seconds=10.0):
-    """Same call signature as the reference.  ``dataloader`` yields
-    ``(((input, ema_input), target), paths)`` batches; returns a DataFrame (or list per threshold) with
-    columns event_label / onset / offset / filename (seconds).  Ground-truth and duration frames are built
-    by the caller's own annotation reader (the reference reads ``annotation/<name>.txt`` next to the features)."""
+    """Same call signature and return value as the reference: ``(predictions, groundtruth_df, duration_df)``.
+    ``dataloader`` yields ``(((input, ema_input), target), paths)`` batches.  predictions: one DataFrame (or a list,
+    one per threshold) with columns event_label / onset / offset / filename (seconds); groundtruth_df: the
+    ``annotation/<name>.txt`` files of the clips concatenated with a ``filename`` column; duration_df: filename /
+    duration (10, as the reference hard-codes it)."""
     import pandas as pd
     if predictor is None:
         raise NotImplementedError("bsed_amd.get_predictions needs the CRNN + Predictor pair (predictor=...)")
@@ -52,32 +90,75 @@ def get_predictions(model, dataloader, decoder, pooling_time_ratio=1, thresholds
         raise NotImplementedError("learned_post (class-wise median windows) is not on the hot path")
     was_training = (model.training, predictor.training)
     model.eval(); predictor.eval()
-    rows = {t: [] for t in thresholds}
+    labels = _decoder_labels(decoder)
+    scale = pooling_time_ratio / (sr / hop_size)
+    frames = {t: [] for t in thresholds}
+    filename_list, annotation_folder_list = [], []
     for i, (((input_data, _ema), _target), paths) in enumerate(dataloader):
         names = [os.path.splitext(os.path.basename(p))[0] for p in paths]
+        folders = [os.path.join(os.path.dirname(os.path.dirname(p)), "annotation") for p in paths]
         with torch.no_grad():
             x = torch.as_tensor(input_data).float().cuda()
             encoded_x, feature_out = model(x)
             pred_strong, _ = predictor(encoded_x, inference=fpn)
         if saved_feature_dir is not None:
             np.save(os.path.join(saved_feature_dir, f"{i}"), feature_out.cpu().numpy())
-        scale = pooling_time_ratio / (sr / hop_size)
         for t in thresholds:
-            # threshold + median filter for the whole batch on the GPU; only the 0/1 masks travel to the host
-            masks = binarize_median_gpu(pred_strong, t, median_window).cpu().numpy()
-            for j, m in enumerate(masks):
-                for lab, on, off in decoder(m):
-                    rows[t].append({"event_label": lab, "onset": float(np.clip(on * scale, 0, max_len_seconds)),
-                                    "offset": float(np.clip(off * scale, 0, max_len_seconds)), "filename": names[j]})
+            mask = binarize_median_gpu(pred_strong, t, median_window)
+            if labels is not None:
+                ev_clip, ev_class, _, ev_sec = decode_regions_gpu(mask, scale, max_len_seconds)
+                frames[t].append(pd.DataFrame({"event_label": np.asarray(labels, dtype=object)[ev_class],
+                                               "onset": ev_sec[:, 0], "offset": ev_sec[:, 1],
+                                               "filename": np.asarray(names, dtype=object)[ev_clip]}))
+            else:
+                # a caller-supplied decoder function can only run on the host, clip by clip
+                rows = []
+                for j, m in enumerate(mask.cpu().numpy()):
+                    for lab, on, off in decoder(m):
+                        rows.append({"event_label": lab, "onset": float(np.clip(on * scale, 0, max_len_seconds)),
+                                     "offset": float(np.clip(off * scale, 0, max_len_seconds)), "filename": names[j]})
+                frames[t].append(pd.DataFrame(rows, columns=["event_label", "onset", "offset", "filename"]))
+        filename_list += names
+        annotation_folder_list += folders
     model.train(was_training[0]); predictor.train(was_training[1])
-    dfs = [pd.DataFrame(rows[t], columns=["event_label", "onset", "offset", "filename"]) for t in thresholds]
+    cols = ["event_label", "onset", "offset", "filename"]
+    dfs = [pd.concat(frames[t], ignore_index=True)[cols] if frames[t] else pd.DataFrame(columns=cols)
+           for t in thresholds]
+
+    # ground-truth and duration frames (reference :226-247): first occurrence of every file name, its annotation file
+    # next to the features, duration 10
+    seen = {}
+    for name, folder in zip(filename_list, annotation_folder_list):
+        seen.setdefault(name, folder)
+    duration_df = pd.DataFrame(list(seen.keys()), columns=["filename"])
+    duration_df["duration"] = 10
+    groundtruth_df = None
+    gts = []
+    for name, folder in seen.items():
+        path = os.path.join(folder, name + ".txt")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"get_predictions: annotation file {path} is missing (the reference reads "
+                                    "annotation/<name>.txt next to wav/<name>.npy)")
+        df = pd.read_csv(path, sep="\t")
+        df["filename"] = name
+        gts.append(df)
+    if gts:
+        groundtruth_df = pd.concat(gts, ignore_index=True)
+
     if save_predictions is not None:
-        outs = [save_predictions] if isinstance(save_predictions, str) and len(dfs) == 1 else save_predictions
-        if isinstance(outs, str):
-            base, ext = os.path.splitext(outs)
-            outs = [os.path.join(base, f"{t:.3f}{ext}") for t in thresholds]
+        if isinstance(save_predictions, str):
+            if len(thresholds) == 1:
+                outs = [save_predictions]
+            else:
+                base, ext = os.path.splitext(save_predictions)
+                outs = [os.path.join(base, f"{t:.3f}{ext}") for t in thresholds]
+        else:
+            assert len(save_predictions) == len(thresholds), \
+                f"There should be a prediction file per threshold: {len(save_predictions)} vs {len(thresholds)}"
+            outs = list(save_predictions)
         for df, path in zip(dfs, outs):
             if os.path.dirname(path):
                 os.makedirs(os.path.dirname(path), exist_ok=True)
             df.to_csv(path, index=False, sep="\t", float_format="%.3f")
-    return dfs[0] if len(dfs) == 1 else dfs
+    predictions = dfs[0] if len(dfs) == 1 else dfs
+    return predictions, groundtruth_df, duration_df

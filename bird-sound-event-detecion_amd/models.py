@@ -83,6 +83,35 @@ class _FlatModule(nn.Module):
             mod = getattr(mod, p)
         return mod
 
+    def reference_param_names(self):
+        """parameter names in the order ``reference_module.parameters()`` yields them: the index space of a
+        torch.optim state_dict written by the reference's scripts (GRU tensors come per layer and direction as
+        weight_ih, weight_hh, bias_ih, bias_hh there; the arena keeps both directions of a kind adjacent)."""
+        own = [n for n, _ in self.named_parameters()]
+        rnn = [n for n in own if ".rnn.weight_" in n or ".rnn.bias_" in n]
+        if not rnn:
+            return own
+        def key(n):
+            pfx, leaf = n.rsplit(".rnn.", 1)
+            rev = leaf.endswith("_reverse")
+            leaf = leaf[:-8] if rev else leaf
+            kind, layer = leaf.rsplit("_l", 1)
+            return (own.index(next(m for m in own if m.startswith(pfx + ".rnn."))), int(layer), rev,
+                    ["weight_ih", "weight_hh", "bias_ih", "bias_hh"].index(kind))
+        first = {}
+        for n in rnn:
+            first.setdefault(n.rsplit(".rnn.", 1)[0], own.index(n))
+        out, done = [], set()
+        for n in own:
+            if n in rnn:
+                pfx = n.rsplit(".rnn.", 1)[0]
+                if pfx not in done:
+                    done.add(pfx)
+                    out += sorted((m for m in rnn if m.rsplit(".rnn.", 1)[0] == pfx), key=key)
+            else:
+                out.append(n)
+        return out
+
     def G(self, dotted):
         return self.P(dotted).grad
 
@@ -469,8 +498,17 @@ class CRNN(_FlatModule):
             raise L.BsedError(f"frequency axis must pool down to 1, got {Ww}")
         return a, Hh
 
-    def _cnn_backward(self, ctx, dpool):
+    TAIL_BLOCKS = 2   # the first CNN blocks' gradients are the last the backward pass writes (parallel.GradArena)
+
+    def tail_grad_floats(self):
+        """floats of flat_grad that belong to the first TAIL_BLOCKS CNN blocks (they lead the arena)"""
+        k = min(self.TAIL_BLOCKS, len(self.nb_filters))
+        return self._poff[f"cnn.conv{k}.weight"] if k < len(self.nb_filters) else self._poff["rnn.rnn.weight_ih_l0"]
+
+    def _cnn_backward(self, ctx, dpool, on_early_grads=None):
         for i in range(len(self.nb_filters) - 1, -1, -1):
+            if on_early_grads is not None and i == min(self.TAIL_BLOCKS, len(self.nb_filters)) - 1:
+                on_early_grads()   # every gradient outside the first TAIL_BLOCKS blocks has been enqueued
             dpool = self._block_backward(ctx["blocks"][i], dpool, ctx["B"], ctx["seed"])
 
     def run_forward(self, x, save=True):
@@ -490,16 +528,20 @@ class CRNN(_FlatModule):
         return enc, ctx
 
     # ------------------------------------------------------------------ backward
-    def run_backward(self, ctx, d_enc):
-        """Accumulates parameter gradients into ``flat_grad``; returns nothing (the input needs no grad)."""
+    def run_backward(self, ctx, d_enc, on_early_grads=None):
+        """Accumulates parameter gradients into ``flat_grad``; returns nothing (the input needs no grad).
+        on_early_grads: called once every gradient except those of the first TAIL_BLOCKS CNN blocks has been enqueued
+        (the data-parallel trainer starts its gradient all-reduce there, overlapping the rest of the backward pass)."""
         B, T = ctx["B"], ctx["T"]
         d = d_enc.contiguous()
         if ctx["drop"] > 0:
             d = ops.dropout(d, ctx["drop"], 200, ctx["seed"])
         d = self._gru_backward(ctx["layers"], d, B, T, "rnn")
         if not self.train_cnn:
+            if on_early_grads is not None:
+                on_early_grads()
             return
-        self._cnn_backward(ctx, d.view(B, T, 1, self.nb_filters[-1]))
+        self._cnn_backward(ctx, d.view(B, T, 1, self.nb_filters[-1]), on_early_grads)
 
     def forward(self, x):
         if torch.is_grad_enabled() and self.training:
@@ -625,7 +667,7 @@ class CRNN_fpn(CRNN):
                        cat1=cat1, cat2=cat2)
         return enc, ctx
 
-    def run_backward(self, ctx, d_enc):
+    def run_backward(self, ctx, d_enc, on_early_grads=None):
         B, T, T2, T4 = ctx["B"], ctx["T"], ctx["T2"], ctx["T4"]
         seed, drop = ctx["seed"], ctx["drop"]
         C = self.nb_filters[-1]
@@ -642,13 +684,15 @@ class CRNN_fpn(CRNN):
                 d = ops.dropout(d, drop, stream, seed)
             d_seq.append(self._gru_backward(layers, d, B, Tl, pfx))
         if not self.train_cnn:
+            if on_early_grads is not None:
+                on_early_grads()
             return
         blk2, blk4 = ctx["fpn_blocks"]
         d_x2 = self._block_backward(blk4, d_seq[2].view(B, T4, 1, C), B, seed)          # dL/d x_2 through level 4
         ops.axpy(d_x2.view(-1), d_seq[1].reshape(-1))                                    # + through rnn_2
         d_a = self._block_backward(blk2, d_x2.view(B, T2, 1, C), B, seed)                # dL/d a through level 2
         ops.axpy(d_a.view(-1), d_seq[0].reshape(-1))                                     # + through rnn
-        self._cnn_backward(ctx, d_a.view(B, T, 1, C))
+        self._cnn_backward(ctx, d_a.view(B, T, 1, C), on_early_grads)
 
 
 class CRNN_pred(CRNN):

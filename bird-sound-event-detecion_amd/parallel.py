@@ -16,6 +16,71 @@ def shard_batch(batch, rank, world):
     return batch[rank::world]
 
 
+class GradArena:
+    """ONE contiguous fp32 gradient buffer for several flat-arena modules (CRNN + Predictor [+ discriminator]).
+
+    Every module's ``flat_grad`` (and through it every parameter's ``.grad``) becomes a view of the arena, laid out as
+    ``[first module | second | ...]``.  ``tail_floats`` leading floats -- the gradients of the first module's first
+    CNN blocks, the ones the backward pass produces LAST -- form the ``tail`` segment, the rest the ``early`` segment:
+
+        begin_early()  all-reduces ``early`` asynchronously as soon as its last gradient has been written (the caller
+                       invokes it from the backward pass, before the first blocks' kernels are enqueued), so the
+                       exchange overlaps the ~25 % of the backward pass that is still to run;
+        finish()       all-reduces the few KB of ``tail`` and waits for both.
+
+    Sums only: the 1/world factor is folded into the optimizer kernel.  With world size 1 both are no-ops (and the
+    arena still makes zero_grad one memset).  SURVEY.md section 8(e); the reference has no distributed code."""
+
+    def __init__(self, modules, tail_floats=0, group=None):
+        self.modules = [m for m in modules if m is not None]
+        self.group = group
+        sizes = [m.flat_grad.numel() for m in self.modules]
+        dev = self.modules[0].flat_grad.device
+        self.flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        off = 0
+        for m, n in zip(self.modules, sizes):
+            view = self.flat[off:off + n]
+            old = m.flat_grad.clone()
+            m.flat_grad = view
+            for _, p in m.named_parameters():
+                p.grad = None                    # _attach_grads rebinds every .grad into the new storage ...
+            m._attach_grads()
+            view.copy_(old)                      # ... and clears an arena it finds unbound: put the values back
+            off += n
+        self.tail_floats = int(tail_floats)
+        self.tail = self.flat[:self.tail_floats]
+        self.early = self.flat[self.tail_floats:]
+        self._work = None
+
+    @property
+    def world(self):
+        if not dist.is_available() or not dist.is_initialized():
+            return 1
+        return dist.get_world_size(self.group)
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def begin_early(self):
+        if self.world == 1 or self._work is not None:
+            return
+        # async_op: the collective runs on the backend's own stream after everything enqueued so far on the current
+        # stream, concurrently with what the caller enqueues next (RCCL); gloo stages through the host instead
+        self._work = dist.all_reduce(self.early, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        if self.world == 1:
+            return
+        if self._work is None:
+            self.begin_early()
+        works = [self._work]
+        if self.tail_floats:
+            works.append(dist.all_reduce(self.tail, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        self._work = None
+
+
 def all_reduce_flat(buffers, group=None, async_op=True):
     """sum-all-reduce each flat buffer in place (no averaging: the optimizer kernel takes 1/world)."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:

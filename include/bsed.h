@@ -334,6 +334,16 @@ int bsed_tag_head_fwd(const float* x, const float* logits, float* strong, float*
 int bsed_binarize_median(const float* strong, float* out, int B, int T, int C, float threshold, int win,
                          void* stream);
 
+/* Contiguous-region decode + frames -> seconds on the GPU (ManyHotEncoder.decode_strong, src/utilities/ManyHotEncoder.py:
+ * 148-164, and src/evaluation_measures.py:205-209).  mask (B,T,C) 0/1 from bsed_binarize_median.
+ *   bsed_decode_count: counts (B*C) = number of on-runs per (clip, class) column;
+ *   bsed_decode_write: offsets (B*C) = exclusive prefix sum of counts (caller's), E = total; writes ev_clip (E),
+ *     ev_class (E), ev_frames (E,2) [onset, offset) and ev_seconds (E,2) = clip(frame * scale, 0, max_len) in float64,
+ *     ordered by clip, class, time -- the reference's row order. */
+int bsed_decode_count(const float* mask, int B, int T, int C, int* counts, void* stream);
+int bsed_decode_write(const float* mask, const int* offsets, int B, int T, int C, double scale, double max_len,
+                      int* ev_clip, int* ev_class, int* ev_frames, double* ev_seconds, void* stream);
+
 typedef struct BsedHeadBwdDesc {
   const float* x;            /* (B,T,K) encoder output */
   const float* w;            /* (2C,K) */

@@ -1,5 +1,6 @@
 """One tiny train step of the hot path on cuda:0, checked against the CPU oracle (used by
-__graft_entry__.smoke(); the oracle is imported here only as the checker)."""
+__graft_entry__.smoke(); test infrastructure: lives under tests/, not in the product package, because it imports
+the oracle as the checker)."""
 import numpy as np
 import torch
 
@@ -7,8 +8,8 @@ import torch
 def run():
     from oracle import crnn_oracle as co
     from oracle import seeded
-    from .engine import FlatAdam, SEDTrainer
-    from .models import CRNN, Predictor
+    from bsed_amd.engine import FlatAdam, SEDTrainer
+    from bsed_amd.models import CRNN, Predictor
     seed, B, T = 3, 2, 64
     kw = dict(co.CRNN_KWARGS)
     kw["dropout"] = 0.0

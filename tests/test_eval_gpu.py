@@ -22,12 +22,27 @@ def test_get_predictions_event_lists_and_feature_dump(tmp_path):
     crnn, pred = CRNN(**co.CRNN_KWARGS), Predictor(**co.PREDICTOR_KWARGS)
     crnn.load_state_dict(ocrnn.state_dict()); pred.load_state_dict(opred.state_dict())
     x = seeded.db_like_input(seed + 2, B, T)
-    loader = [(((torch.from_numpy(x), torch.from_numpy(x)), None), [f"/d/wav/clip{i}.npy" for i in range(B)])]
+    # the reference's layout: <root>/wav/<name>.npy with <root>/annotation/<name>.txt next to it
+    root = tmp_path / "d"
+    (root / "wav").mkdir(parents=True); (root / "annotation").mkdir()
+    truth = {0: [(1.0, 3.5, "EATO"), (4.0, 4.5, "AMCR")], 1: [], 2: [(0.0, 9.9, "BAWW")]}
+    for i in range(B):
+        with open(root / "annotation" / f"clip{i}.txt", "w") as f:
+            f.write("onset\toffset\tevent_label\n")
+            for on, off, lab in truth[i]:
+                f.write(f"{on}\t{off}\t{lab}\n")
+    loader = [(((torch.from_numpy(x), torch.from_numpy(x)), None), [str(root / "wav" / f"clip{i}.npy") for i in range(B)])]
     enc = ManyHotEncoder(BIRD_LIST, n_frames=T // 4)
     feat_dir = tmp_path / "feat"; feat_dir.mkdir()
-    df = get_predictions(crnn, loader, enc.decode_strong, pooling_time_ratio=4, thresholds=[0.5], median_window=5,
-                         predictor=pred, saved_feature_dir=str(feat_dir),
-                         save_predictions=str(tmp_path / "pred.tsv"))
+    df, gt_df, dur_df = get_predictions(crnn, loader, enc.decode_strong, pooling_time_ratio=4, thresholds=[0.5],
+                                        median_window=5, predictor=pred, saved_feature_dir=str(feat_dir),
+                                        save_predictions=str(tmp_path / "pred.tsv"))
+    # the reference's three return values (src/evaluation_measures.py:226-247,283)
+    assert list(dur_df.columns) == ["filename", "duration"] and list(dur_df.filename) == ["clip0", "clip1", "clip2"]
+    assert (dur_df.duration == 10).all()
+    assert list(gt_df.columns) == ["onset", "offset", "event_label", "filename"]
+    assert [(r.onset, r.offset, r.event_label, r.filename) for r in gt_df.itertuples()] == \
+        [(1.0, 3.5, "EATO", "clip0"), (4.0, 4.5, "AMCR", "clip0"), (0.0, 9.9, "BAWW", "clip2")]
     ocrnn.eval(); opred.eval()
     with torch.no_grad():
         e, _ = ocrnn(torch.from_numpy(x))
@@ -37,8 +52,34 @@ def test_get_predictions_event_lists_and_feature_dump(tmp_path):
         for lab, on, off in lo.post_process(strong[j].numpy(), median_window=5):
             ref.append((lab, round(on, 6), round(off, 6), f"clip{j}"))
     got = [(r.event_label, round(r.onset, 6), round(r.offset, 6), r.filename) for r in df.itertuples()]
-    assert len(ref) > 0 and sorted(got) == sorted(ref)
+    assert len(ref) > 0 and got == ref        # same rows in the reference's order: clip, class, time
+    # a plain function as decoder takes the host path and must give the same list
+    df2, _, _ = get_predictions(crnn, loader, lambda m: enc.decode_strong(m), pooling_time_ratio=4, thresholds=[0.5],
+                                median_window=5, predictor=pred)
+    assert [(r.event_label, r.onset, r.offset, r.filename) for r in df2.itertuples()] == \
+        [(r.event_label, r.onset, r.offset, r.filename) for r in df.itertuples()]
     dumped = np.load(feat_dir / "0.npy")
     np.testing.assert_allclose(dumped, e.numpy(), atol=1e-4)
     assert (tmp_path / "pred.tsv").exists()
     assert crnn.training and pred.training  # restored
+
+
+def test_decode_regions_gpu_matches_decode_strong_bit_exactly():
+    """contiguous regions + seconds on the GPU against ManyHotEncoder.decode_strong / the reference's float64
+    conversion, including columns that start on, end on, are empty, are full, and single-frame runs"""
+    from bsed_amd.evaluation import decode_regions_gpu
+    rng = np.random.default_rng(3)
+    for B, T, C in ((3, 313, 20), (2, 216, 20), (5, 7, 3), (1, 1, 20)):
+        m = (rng.random((B, T, C)) < 0.3).astype(np.float32)
+        m[0, :, 0] = 1.0
+        m[0, :, min(1, C - 1)] = 0.0 if C > 1 else 1.0
+        if T > 2 and C > 2:
+            m[-1, 0, 2] = 1.0; m[-1, 1, 2] = 0.0; m[-1, -1, 2] = 1.0
+        scale = 4 / (32000 / 255)
+        ev_clip, ev_class, ev_frames, ev_sec = decode_regions_gpu(torch.from_numpy(m).cuda(), scale, 10.0)
+        want = [(b, c, int(on), int(off)) for b in range(B) for c in range(C)
+                for on, off in lo.find_contiguous_regions(m[b, :, c])]
+        got = [(int(b), int(c), int(f[0]), int(f[1])) for b, c, f in zip(ev_clip, ev_class, ev_frames)]
+        assert got == want, (B, T, C)
+        sec = np.clip(np.asarray([[w[2], w[3]] for w in want], dtype=np.float64).reshape(-1, 2) * scale, 0, 10.0)
+        assert ev_sec.dtype == np.float64 and np.array_equal(ev_sec, sec)

@@ -32,9 +32,10 @@ def test_fpn_eval_forward_matches_reference_golden(golden_dir, conv_mode):
     g = np.load(os.path.join(golden_dir, "crnn_fpn.npz"))
     B, T, seed = (int(v) for v in g["meta"])
     ref, mine = _pair(0.5, seed, conv_mode)
-    # same state-dict entries as the reference module (its "cnn.cnn." level is the CRNN's documented key quirk)
-    want = sorted(str(n).replace("cnn.cnn.", "cnn.", 1) if str(n).startswith("cnn.cnn.") else str(n) for n in g["state_names"])
-    assert sorted(mine.state_dict().keys()) == want
+    # exactly the reference module's state-dict entries, "cnn.cnn.conv0.weight" next to "cnn.cnn_fcn.weight" included
+    # (CNN_FPN keeps its Sequential's level; the plain CRNN's CNN strips it)
+    assert sorted(mine.state_dict().keys()) == sorted(str(n) for n in g["state_names"])
+    assert isinstance(mine.load_state_dict(mine.state_dict()).missing_keys, list)   # both spellings load
     mine.eval()
     x = torch.from_numpy(seeded.db_like_input(seed + 10, B, T)).cuda()
     with torch.no_grad():
