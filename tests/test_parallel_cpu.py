@@ -10,6 +10,14 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
+def _toy_module(specs):
+    """a bsed_amd.models._FlatModule built on CPU storage (the GPU check of its constructor is what the real modules add)"""
+    from bsed_amd.models import _FlatModule
+    m = _FlatModule()
+    m._build(specs, [], "cpu")
+    return m
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -36,8 +44,24 @@ def _worker(rank, world, port, q):
     ((X @ Wf.T + bf - Y) ** 2).mean().backward()
     g_full = torch.cat([Wf.grad.flatten(), bf.grad, torch.zeros(4)])
     tmax = parallel.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    # GradArena: two flat-arena modules (the real _FlatModule class on CPU storage) share ONE gradient buffer; the
+    # exchange runs as early segment (started "inside the backward pass") + tail segment
+    mods = [_toy_module([("cnn.conv0.weight", (4, 3)), ("cnn.conv1.weight", (5,)), ("rnn.w", (6, 2))]),
+            _toy_module([("dense.weight", (3, 3))])]
+    arena = parallel.GradArena(mods, tail_floats=12)
+    assert arena.flat.numel() == 12 + 5 + 12 + 9 and arena.tail.numel() == 12
+    assert all(p.grad.data_ptr() >= arena.flat.data_ptr() for m in mods for p in m.parameters())
+    for k, m in enumerate(mods):
+        for j, p in enumerate(m.parameters()):
+            p.grad.fill_(float(rank + 1) * (10 * k + j + 1))
+    arena.begin_early()
+    arena.finish()
+    want = torch.cat([torch.full((12,), 3.0), torch.full((5,), 6.0), torch.full((12,), 9.0), torch.full((9,), 33.0)])
+    arena_ok = bool(torch.equal(arena.flat, want)) and bool(torch.equal(mods[1].flat_grad, torch.full((9,), 33.0)))
+    arena.zero_()
+    arena_ok = arena_ok and float(mods[0].P("rnn.w").grad.abs().sum()) == 0.0
     q.put((rank, flat.numpy().copy(), float((g_dp - g_full).abs().max()), tmax,
-           parallel.shard_indices(7, rank, world), parallel.rank_seed(2023, 5, rank)))
+           parallel.shard_indices(7, rank, world), parallel.rank_seed(2023, 5, rank), arena_ok))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -54,7 +78,8 @@ def test_two_rank_data_parallel_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, flat0, e0, t0, idx0, s0), (r1, flat1, e1, t1, idx1, s1) = res
+    (r0, flat0, e0, t0, idx0, s0, a0), (r1, flat1, e1, t1, idx1, s1, a1) = res
+    assert a0 and a1                                      # one-arena exchange: every parameter's .grad summed over ranks
     np.testing.assert_array_equal(flat0, flat1)           # broadcast made the replicas identical
     assert e0 < 1e-6 and e1 < 1e-6                        # sum-all-reduce * 1/world == full-batch gradient
     assert t0 == t1 == 2.0                                # max over ranks
@@ -64,6 +89,12 @@ def test_two_rank_data_parallel_gloo():
 
 def test_single_process_helpers_are_noops():
     from bsed_amd import parallel
+    m = _toy_module([("a.weight", (2, 2)), ("b.weight", (3,))])
+    m.flat_grad.copy_(torch.arange(7.0))
+    arena = parallel.GradArena([m], tail_floats=4)
+    assert torch.equal(arena.flat, torch.arange(7.0)) and torch.equal(m.P("b.weight").grad, torch.tensor([4.0, 5.0, 6.0]))
+    arena.begin_early(); arena.finish()                   # world size 1: nothing to exchange
+    assert torch.equal(arena.flat, torch.arange(7.0))
     g = torch.ones(5)
     assert parallel.all_reduce_flat([g]) == [] and torch.equal(g, torch.ones(5))
     parallel.broadcast_flat([g])
