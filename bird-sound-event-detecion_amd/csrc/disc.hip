@@ -1,7 +1,9 @@
 // Clip-level domain discriminator pieces (reference Clip_Discriminator, src/models/CRNN_GRL.py:16-53, fed through
 // the gradient-reverse layer of src/DA/grl.py:12-22 and the BCE of src/DA/cdan_frame.py:89-119).
 //
-// The five 3x3 / stride-2 / pad-0 convolutions are lowered to GEMMs on the existing fp32-MFMA kernels:
+// Layers 2 and 3 (128 -> 64 -> 32 channels: 98 % of the discriminator's multiply-adds) run DIRECTLY on the implicit-GEMM
+// kernels through a space-to-depth re-layout (s2d_* below).  Layers 1, 4 and 5 (1, 32 and 16 input channels: too few
+// for a 32-channel K chunk) keep the im2col lowering:
 //   forward   y = im2col(act) @ W            (bsed_igemm, BSED_EPI_STATS for the BatchNorm statistics)
 //   weights   dW = im2col(act)^T @ dY         (bsed_wgrad)
 //   data      d_act = col2im(dY @ W^T)        (bsed_igemm + col2im)
@@ -148,6 +150,89 @@ __global__ __launch_bounds__(256) void col2im_s2_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Direct form of the stride-2 convolutions (no im2col matrix): space-to-depth.
+//   Y[i][j] = sum_{kh,kw,c} W[kh][kw][c] A[2i+kh][2j+kw][c]  with  2i+kh = 2(i + (kh>>1)) + (kh&1):
+//   X'[p][q][(a*2+b)*C + c] = A[2p+a][2q+b][c]  turns it into a 2x2 stride-1 convolution over 4C channels whose taps
+//   (dp,dq) in {0,1}^2 carry W[2dp+a][2dq+b] (zero where 2dp+a or 2dq+b would be 3).  16/9 of the multiply-adds, but
+//   the operand is the activation itself (re-laid out once, with the previous layer's BatchNorm + LeakyReLU fused)
+//   instead of a 9x larger gathered copy that four GEMM passes stream through HBM.
+// s2d_fwd_kernel : y (N,Ha,Wa,C) allocated, valid extent Hi x Wi -> X' (N,Hp,Wp,4C); one float4 of channels per thread
+// s2d_bwd_kernel : dX' -> g over the allocated grid of y (LeakyReLU' applied, zero outside the valid extent) + per-block
+//                  (sum g, sum g*y) partials, same slot logic as col2im_s2_kernel
+// ---------------------------------------------------------------------------------------------
+__global__ void s2d_fwd_kernel(const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                               float* __restrict__ xp, int N, int Ha, int Wa, int Hi, int Wi, int C, int Hp, int Wp) {
+  const int cq = C / 4;
+  const long total = (long)N * Hp * Wp * 4 * cq;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % cq);
+    long r = e / cq;
+    const int ab = (int)(r & 3); r >>= 2;
+    const int q = (int)(r % Wp); r /= Wp;
+    const int pp = (int)(r % Hp);
+    const long n = r / Hp;
+    const int h = 2 * pp + (ab >> 1), w = 2 * q + (ab & 1), c = 4 * c4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h < Hi && w < Wi) {
+      v = *reinterpret_cast<const float4*>(y + ((n * Ha + h) * Wa + w) * (long)C + c);
+      if (scale) {
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+        v.x = v.x > 0.f ? v.x : LEAKY * v.x; v.y = v.y > 0.f ? v.y : LEAKY * v.y;
+        v.z = v.z > 0.f ? v.z : LEAKY * v.z; v.w = v.w > 0.f ? v.w : LEAKY * v.w;
+      }
+    }
+    *reinterpret_cast<float4*>(xp + e * 4) = v;   // e enumerates X' in memory order: [n][p][q][a*2+b][c]
+  }
+}
+
+__global__ __launch_bounds__(256) void s2d_bwd_kernel(const float* __restrict__ dxp, const float* __restrict__ y,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      float* __restrict__ g_out, float* __restrict__ stats, int N, int Ha,
+                                                      int Wa, int Hi, int Wi, int C, int Hp, int Wp) {
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x;
+  const int cq = C / 4;
+  const long tot = (long)N * Ha * Wa * cq;
+  const long e = (long)blockIdx.x * 256 + tid;   // not grid-strided: the partial-stat slot is the block's own
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f), gy = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < tot) {
+    const int c4 = (int)(e % cq), c = 4 * c4;
+    long r = e / cq;
+    const int w = (int)(r % Wa); r /= Wa;
+    const int h = (int)(r % Ha);
+    const long n = r / Ha;
+    if (h < Hi && w < Wi) {
+      const float4 a = *reinterpret_cast<const float4*>(
+          dxp + ((((n * Hp + (h >> 1)) * Wp + (w >> 1)) * 4 + ((h & 1) * 2 + (w & 1))) * (long)C + c));
+      const float4 yv = *reinterpret_cast<const float4*>(y + e * 4);
+      const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+      const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+      g.x = a.x * (fmaf(yv.x, sc.x, sh.x) > 0.f ? 1.f : LEAKY);
+      g.y = a.y * (fmaf(yv.y, sc.y, sh.y) > 0.f ? 1.f : LEAKY);
+      g.z = a.z * (fmaf(yv.z, sc.z, sh.z) > 0.f ? 1.f : LEAKY);
+      g.w = a.w * (fmaf(yv.w, sc.w, sh.w) > 0.f ? 1.f : LEAKY);
+      gy = make_float4(g.x * yv.x, g.y * yv.y, g.z * yv.z, g.w * yv.w);
+    }
+    *reinterpret_cast<float4*>(g_out + e * 4) = g;
+  }
+  float* r8 = red + tid * 8;
+  r8[0] = g.x; r8[1] = g.y; r8[2] = g.z; r8[3] = g.w; r8[4] = gy.x; r8[5] = gy.y; r8[6] = gy.z; r8[7] = gy.w;
+  __syncthreads();
+  if (tid < 2 * C) {
+    const int which = tid / C, ch = tid % C;
+    const int q0 = (int)(((long)blockIdx.x * 256) % cq);
+    float s = 0.f;
+    int t0 = (ch / 4 - q0) % cq;
+    if (t0 < 0) t0 += cq;
+    for (int t = t0; t < 256; t += cq) s += red[t * 8 + which * 4 + (ch & 3)];
+    stats[((size_t)blockIdx.x * 2 + which) * C + ch] = s;
+  }
+}
+
 // tail of the discriminator for one sample per thread: y5 (N,H5,W5,8) -> BN + LeakyReLU -> AdaptiveAvgPool over the
 // feature axis (W5 = 7 -> bins [0,4), [3,7)) and all of time -> Linear(16,1) -> sigmoid -> BCE(label_n), and back.
 __global__ void disc_head_kernel(const float* __restrict__ y5, const float* __restrict__ scale,
@@ -251,6 +336,35 @@ extern "C" int bsed_col2im_s2(const float* dcol, const float* y, const float* sc
     hipLaunchKernelGGL(col2im_s2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dcol, y, scale, shift, out, stats, N, Hi,
                        Wi, C, CP, 9 * CP, Ho, Wo, out_scale);
   }
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_s2d_fwd(const float* y, const float* scale, const float* shift, float* xp, int N, int Ha, int Wa, int Hi,
+                            int Wi, int C, void* stream) {
+  BSED_CHECK_ARG(y && xp && N > 0 && Hi >= 3 && Wi >= 3 && Ha >= Hi && Wa >= Wi, "bsed_s2d_fwd: bad argument");
+  BSED_CHECK_ARG(C % 4 == 0 && C >= 4, "bsed_s2d_fwd: C must be a multiple of 4");
+  BSED_CHECK_ARG((scale == nullptr) == (shift == nullptr), "bsed_s2d_fwd: scale/shift come together");
+  const int Hp = (Hi + 1) / 2, Wp = (Wi + 1) / 2;
+  const long total = (long)N * Hp * Wp * C;
+  hipLaunchKernelGGL(s2d_fwd_kernel, dim3((unsigned)std::min<long>(ceil_div(total, 256), 32768)), dim3(256), 0,
+                     (hipStream_t)stream, y, scale, shift, xp, N, Ha, Wa, Hi, Wi, C, Hp, Wp);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_s2d_num_blocks(int N, int Ha, int Wa, int C) { return ceil_div((long)N * Ha * Wa * (C / 4), 256); }
+
+extern "C" int bsed_s2d_bwd(const float* dxp, const float* y, const float* scale, const float* shift, float* g, float* stats,
+                            int N, int Ha, int Wa, int Hi, int Wi, int C, void* stream) {
+  BSED_CHECK_ARG(dxp && y && scale && shift && g && stats && N > 0 && Ha >= Hi && Wa >= Wi && Hi >= 3 && Wi >= 3,
+                 "bsed_s2d_bwd: bad argument");
+  BSED_CHECK_ARG(C % 4 == 0 && 256 % (C / 4) == 0 && C <= 128, "bsed_s2d_bwd: C must be 16..128, a power of two");
+  const int Hp = (Hi + 1) / 2, Wp = (Wi + 1) / 2;
+  const long blocks = ceil_div((long)N * Ha * Wa * (C / 4), 256);
+  BSED_CHECK_ARG(blocks < (1L << 31), "bsed_s2d_bwd: too many blocks");
+  hipLaunchKernelGGL(s2d_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dxp, y, scale, shift, g,
+                     stats, N, Ha, Wa, Hi, Wi, C, Hp, Wp);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_kernel(const IgemmParams P) 
       const int r = rg * 4 + rr;
       const int mm = wave * 32 + crow(r, lh);
       const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
-      const bool pok = gh < p.H && gw < p.W;
+      const bool pok = gh < (p.valid_h > 0 ? p.valid_h : p.H) && gw < (p.valid_w > 0 ? p.valid_w : p.W);
       const size_t pos = ((size_t)nb * p.H + gh) * p.W + gw;
       mmv[rr] = mm; pokv[rr] = pok; posv[rr] = pos;
       bool pooled_ok = false;

@@ -188,7 +188,7 @@ void igemm3_kernel(const Igemm3Params P) {
     for (int r = 0; r < 16; ++r) {
       const int mm = (wave * RB + rb) * 32 + crow3(r, lh);
       const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
-      const bool pok = gh < p.H && gw < p.W;
+      const bool pok = gh < (p.valid_h > 0 ? p.valid_h : p.H) && gw < (p.valid_w > 0 ? p.valid_w : p.W);
       float* orow = p.out + (((size_t)nb * p.H + gh) * p.W + gw) * p.out_pitch + nbase;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {

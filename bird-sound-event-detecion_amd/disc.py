@@ -4,7 +4,9 @@
   ConditionalDomainAdversarialLoss(discriminator)      <- reference src/DA/cdan_frame.py:16-119 as it executes:
         d = D(GRL_lambda(cat(f_s, f_t)));  loss = BCE(d, [1]*B_s + [0]*B_t)
         lambda_i = 2/(1+exp(-i/1000)) - 1, i += 1 per call   (WarmStartGradientReverseLayer, src/DA/grl.py:33-73)
-The convolutions run as im2col + the fp32-MFMA GEMM kernels (csrc/disc.hip, csrc/igemm.hip).
+Layers 2 and 3 (98 % of the multiply-adds) run directly on the implicit-GEMM kernels through a space-to-depth
+re-layout (a 3x3 / stride-2 convolution is a 2x2 / stride-1 one over 4C channels); layers 1, 4 and 5 (1, 32, 16 input
+channels) keep the im2col lowering (csrc/disc.hip, csrc/igemm.hip, csrc/igemm3.hip).
 """
 import ctypes
 import math
@@ -49,6 +51,32 @@ def _col2im(dcol, y, scale, shift, N, Hi, Wi, C, CP, out_scale=1.0):
     L.call("bsed_col2im_s2", L.ptr(dcol), L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(out), L.ptr(stats), _i(N), _i(Hi),
            _i(Wi), _i(C), _i(CP), ctypes.c_float(out_scale), L.stream())
     return out, stats
+
+
+TAPS2x2 = [(0, 0), (0, 1), (1, 0), (1, 1)]
+# weight slot ((dp*2+dq)*2+a)*2+b of the space-to-depth form holds W[kh = 2dq+b][kw = 2dp+a] (image rows = time pair
+# with the reference's kw, image columns = features with its kh: the image is kept in the embedding's (T, 256) order)
+_S2D_SLOT = [(((kw >> 1) * 2 + (kh >> 1)) * 2 + (kw & 1)) * 2 + (kh & 1) for kh in range(3) for kw in range(3)]
+DIRECT_LAYERS = (2, 3)
+
+
+def _s2d_fwd(y, scale, shift, N, Ha, Wa, Hi, Wi, C):
+    Hp, Wp = (Hi + 1) // 2, (Wi + 1) // 2
+    xp = torch.empty((N, Hp, Wp, 4 * C), device=y.device, dtype=torch.float32)
+    ops._note("s2d_fwd_kernel", f"{Hi}x{Wi}x{C}", 3.0 * xp.numel(), 4.0 * (N * Hi * Wi * C + xp.numel()))
+    L.call("bsed_s2d_fwd", L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(xp), _i(N), _i(Ha), _i(Wa), _i(Hi), _i(Wi), _i(C),
+           L.stream())
+    return xp, Hp, Wp
+
+
+def _s2d_bwd(dxp, y, scale, shift, N, Ha, Wa, Hi, Wi, C):
+    g = torch.empty((N, Ha, Wa, C), device=y.device, dtype=torch.float32)
+    nb = L.lib().bsed_s2d_num_blocks(N, Ha, Wa, C)
+    stats = torch.empty((nb, 2, C), device=y.device, dtype=torch.float32)
+    ops._note("s2d_bwd_kernel", f"{Hi}x{Wi}x{C}", 4.0 * g.numel(), 4.0 * (N * Hi * Wi * C + 2 * g.numel()))
+    L.call("bsed_s2d_bwd", L.ptr(dxp), L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(g), L.ptr(stats), _i(N), _i(Ha), _i(Wa),
+           _i(Hi), _i(Wi), _i(C), L.stream())
+    return g, stats
 
 
 class Clip_Discriminator(_FlatModule):
@@ -127,39 +155,70 @@ class Clip_Discriminator(_FlatModule):
             full[0, :co, :K] = tmp.view(co, K)
         return full, K, cop
 
+    def _s2d_weight(self, k):
+        """(4 taps, 4*cin, co) weight of the space-to-depth form of conv_k: slot (dp,dq,a,b) = W[2dq+b][2dp+a] or zero"""
+        co, cin = D_CH[k], D_CH[k - 1]
+        w = self.P(f"conv_{k}.weight").detach()
+        full = torch.zeros((16, cin, co), device=w.device, dtype=torch.float32)
+        full[_S2D_SLOT] = w.permute(2, 3, 1, 0).reshape(9, cin, co)
+        return full.view(4, 4 * cin, co)
+
     def run_forward(self, feat, n_source=None, save=True):
         """feat (N,T,256) -> (d (N,), ctx).  In train mode (and with n_source) also prepares the BCE backward."""
         feat = feat.contiguous().float()
         N, T, F = feat.shape
+        if F != 256:
+            raise L.BsedError(f"Clip_Discriminator is built for 256-feature encodings (2 x 128 GRU cells), got {F}")
         train = self.training
+        # act: pre-BatchNorm output of the previous layer on an ALLOCATED grid (Ha, Wa) whose VALID extent is (Hi, Wi)
         act, scale, shift = feat, None, None
-        Hi, Wi = T, F
+        Ha, Wa, Hi, Wi = T, F, T, F
         layers = []
         for k in range(1, 6):
             co, cin = D_CH[k], D_CH[k - 1]
-            wpk, CP = self._fwd_weight(k)
-            col, Ho, Wo, K = _im2col(act, scale, shift, N, Hi, Wi, cin, CP)
-            M = N * Ho * Wo
             epi = ops.EPI_STATS if train else ops.EPI_PLAIN
-            if self.conv_mode == "bf16x3" and K % 32 == 0:
-                # split-fp32 operands on the bf16 matrix cores (the 9x larger col matrix makes these GEMMs HBM-bound:
-                # what counts is that the kernel streams, which the fp32-core GEMM does not at K = 1152)
-                w3 = ops.pack_weight3(wpk, 1, K, co, 0, wpk.shape[2], 1)
-                y, stats = ops.igemm3(col, w3, co, 1, M, 1, K, ((0, 0),), bias=self.P(f"conv_{k}.bias"), epilogue=epi)
+            bias = self.P(f"conv_{k}.bias")
+            Ho, Wo = (Hi - 3) // 2 + 1, (Wi - 3) // 2 + 1
+            M = N * Ho * Wo
+            if k in DIRECT_LAYERS:
+                xp, Hp, Wp = _s2d_fwd(act, scale, shift, N, Ha, Wa, Hi, Wi, cin)
+                assert (Hp - 1, Wp - 1) == (Ho, Wo)
+                wfull = self._s2d_weight(k)
+                K = 4 * cin
+                if self.conv_mode == "bf16x3":
+                    w3 = ops.pack_weight3(wfull, 4, K, co, K * co, co, 1)
+                    y, stats = ops.igemm3(xp, w3, co, N, Hp, Wp, K, TAPS2x2, bias=bias, epilogue=epi, valid=(Ho, Wo))
+                else:
+                    wpk = ops.pack_weight(wfull, 4, K, co, K * co, co, 1)
+                    y, stats = ops.igemm(xp, wpk, co, N, Hp, Wp, K, taps=TAPS2x2, bias=bias, epilogue=epi, valid=(Ho, Wo))
+                rec = dict(direct=True, xp=xp, wfull=wfull, Hp=Hp, Wp=Wp)
+                nHa, nWa = Hp, Wp
             else:
-                y, stats = ops.igemm(col, wpk, co, 1, M, 1, K, bias=self.P(f"conv_{k}.bias"), epilogue=epi)
+                if (Ha, Wa) != (Hi, Wi):  # compact copy of the valid extent for the im2col gather (small layers only)
+                    act = act[:, :Hi, :Wi, :].contiguous()
+                wpk, CP = self._fwd_weight(k)
+                col, Ho_, Wo_, K = _im2col(act, scale, shift, N, Hi, Wi, cin, CP)
+                if self.conv_mode == "bf16x3" and K % 32 == 0:
+                    w3 = ops.pack_weight3(wpk, 1, K, co, 0, wpk.shape[2], 1)
+                    y, stats = ops.igemm3(col, w3, co, 1, M, 1, K, ((0, 0),), bias=bias, epilogue=epi)
+                else:
+                    y, stats = ops.igemm(col, wpk, co, 1, M, 1, K, bias=bias, epilogue=epi)
+                y = y.view(N, Ho, Wo, co)
+                rec = dict(direct=False, col=col, K=K, CP=CP)
+                nHa, nWa = Ho, Wo
             bn = self.P(f"bn_{k}")
             if train:
-                mean, invstd, scale, shift = ops.bn_finalize(stats, co, float(M), D_EPS, D_MOM, bn.weight, bn.bias,
-                                                             bn.running_mean, bn.running_var, self.nbt[k - 1:k])
+                mean, invstd, nscale, nshift = ops.bn_finalize(stats, co, float(M), D_EPS, D_MOM, bn.weight, bn.bias,
+                                                               bn.running_mean, bn.running_var, self.nbt[k - 1:k])
             else:
                 mean = invstd = None
-                scale, shift = ops.bn_eval(co, D_EPS, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-            y = y.view(N, Ho, Wo, co)
+                nscale, nshift = ops.bn_eval(co, D_EPS, bn.weight, bn.bias, bn.running_mean, bn.running_var)
             if save:
-                layers.append(dict(col=col, y=y, mean=mean, invstd=invstd, scale=scale, shift=shift, Hi=Hi, Wi=Wi,
-                                   Ho=Ho, Wo=Wo, K=K, CP=CP, M=M))
-            act, Hi, Wi = y, Ho, Wo
+                rec.update(y=y, mean=mean, invstd=invstd, scale=nscale, shift=nshift, Ha_in=Ha, Wa_in=Wa, Hi=Hi, Wi=Wi,
+                           Ho=Ho, Wo=Wo, Ha=nHa, Wa=nWa, M=M)
+                layers.append(rec)
+            act, scale, shift = y, nscale, nshift
+            Ha, Wa, Hi, Wi = nHa, nWa, Ho, Wo
         dev = feat.device
         d = torch.empty((N,), device=dev, dtype=torch.float32)
         do_loss = train and n_source is not None
@@ -186,6 +245,7 @@ class Clip_Discriminator(_FlatModule):
         dense = self.P("dense_d")
         ops.stats_to_grad(ctx["dwl"], 16, 0, dense.weight.grad)
         ops.stats_to_grad(ctx["dbl"], 1, 0, dense.bias.grad)
+        # g: dL/d(BatchNorm_k output pre-activation side), on layer k's allocated grid; stats: its (sum g, sum g*y) partials
         g, stats = ctx["g5"], ctx["stats5"]
         for k in range(5, 0, -1):
             l = lay[k - 1]
@@ -193,8 +253,28 @@ class Clip_Discriminator(_FlatModule):
             bn = self.P(f"bn_{k}")
             ops.bn_bwd(stats, co, float(l["M"]), bn.weight, l["mean"], l["invstd"], bn.weight.grad, bn.bias.grad, g,
                        l["y"])
-            dy = g.view(l["M"], co)
             w = self.P(f"conv_{k}.weight")
+            p = lay[k - 2] if k > 1 else None
+            if l["direct"]:
+                Hp, Wp, K = l["Hp"], l["Wp"], 4 * cin
+                dy = g.view(N, Hp, Wp, co)
+                # the BatchNorm-backward map is affine: it left non-zero values on the grid's non-output row / column
+                dy[:, l["Ho"]:, :, :] = 0
+                dy[:, :, l["Wo"]:, :] = 0
+                part, G, KP, NP = ops.wgrad(l["xp"], dy, N, Hp, Wp, K, co, taps=TAPS2x2)
+                tmp = torch.empty((4, K, co), device=dy.device, dtype=torch.float32)
+                ops.reduce_partials(part, G, 4, KP, NP, K, co, tmp, K * co, co, 1, accumulate=False)
+                w.grad.add_(tmp.view(16, cin, co)[_S2D_SLOT].permute(2, 1, 0).reshape(co, cin, 3, 3))
+                flipped = [(-a, -b) for a, b in TAPS2x2]
+                if self.conv_mode == "bf16x3":
+                    wd3 = ops.pack_weight3(l["wfull"], 4, co, K, K * co, 1, co)
+                    dxp, _ = ops.igemm3(dy, wd3, K, N, Hp, Wp, co, flipped)
+                else:
+                    wd = ops.pack_weight(l["wfull"], 4, co, K, K * co, 1, co)
+                    dxp, _ = ops.igemm(dy, wd, K, N, Hp, Wp, co, taps=flipped)
+                g, stats = _s2d_bwd(dxp, p["y"], p["scale"], p["shift"], N, l["Ha_in"], l["Wa_in"], l["Hi"], l["Wi"], cin)
+                continue
+            dy = g.view(l["M"], co)
             part, G, KP, NP = ops.wgrad(l["col"], dy, 1, l["M"], 1, l["K"], co)
             if cin == 1:
                 ops.reduce_partials(part, G, 1, KP, NP, 9, co, w.grad, 0, 1, 9)
@@ -212,8 +292,14 @@ class Clip_Discriminator(_FlatModule):
             else:
                 dcol, _ = ops.igemm(dy, wT, K, 1, l["M"], 1, cop)
             if k > 1:
-                p = lay[k - 2]
-                g, stats = _col2im(dcol, p["y"], p["scale"], p["shift"], N, l["Hi"], l["Wi"], cin, l["CP"])
+                # gradient on the compact (Hi, Wi) extent of the previous layer's output ...
+                yc = p["y"] if (p["Ha"], p["Wa"]) == (l["Hi"], l["Wi"]) else p["y"][:, :l["Hi"], :l["Wi"], :].contiguous()
+                gc, stats = _col2im(dcol, yc, p["scale"], p["shift"], N, l["Hi"], l["Wi"], cin, l["CP"])
+                if (p["Ha"], p["Wa"]) == (l["Hi"], l["Wi"]):
+                    g = gc
+                else:  # ... put back on that layer's allocated grid (zero on its non-output row / column)
+                    g = torch.zeros((N, p["Ha"], p["Wa"], cin), device=gc.device, dtype=torch.float32)
+                    g[:, :l["Hi"], :l["Wi"], :] = gc
             else:
                 dfeat, _ = _col2im(dcol, None, None, None, N, l["Hi"], l["Wi"], 1, 1, out_scale=-float(grl_coeff))
         return dfeat.view(N, ctx["T"], ctx["F"])

@@ -20,7 +20,8 @@ class IgemmDesc(ctypes.Structure):
                                      "tilesH", "tilesW", "hh", "hw", "ntaps")]
                 + [("dh", _i * 9), ("dw", _i * 9)]
                 + [(n, _i) for n in ("ph", "pw", "Hp", "Wp", "epilogue")]
-                + [("drop_p", ctypes.c_float), ("rng_stream", ctypes.c_uint32), ("seed", ctypes.c_uint64)])
+                + [("drop_p", ctypes.c_float), ("rng_stream", ctypes.c_uint32), ("seed", ctypes.c_uint64)]
+                + [("valid_h", _i), ("valid_w", _i)])
 
 
 class WgradDesc(ctypes.Structure):
@@ -147,8 +148,9 @@ def pack_weight(src, ntaps, K, N, s_tap, s_k, s_n, src_offset=0):
 
 def igemm(inp, wpk, N, NB, H, W, CIN, taps=((0, 0),), bias=None, out=None, epilogue=EPI_PLAIN, in_pitch=None,
           out_pitch=None, a_scale=None, a_shift=None, e_src=None, e_scale=None, e_shift=None, e_dpool=None,
-          out2=None, pool=(1, 1), drop_p=0.0, rng_stream=0, seed=0, in_offset=0, want_stats=False):
-    """Launch the implicit GEMM.  Returns (out, stats or None)."""
+          out2=None, pool=(1, 1), drop_p=0.0, rng_stream=0, seed=0, in_offset=0, want_stats=False, valid=None):
+    """Launch the implicit GEMM.  Returns (out, stats or None).  valid = (h, w): only output positions inside that
+    extent are stored / enter the STATS sums (the rest of a freshly allocated ``out`` is zero)."""
     d = IgemmDesc()
     TH, TW = tile_for(W)
     NP = wpk.shape[2]
@@ -157,7 +159,9 @@ def igemm(inp, wpk, N, NB, H, W, CIN, taps=((0, 0),), bias=None, out=None, epilo
     dev = inp.device
     if out is None:
         shape = (NB, Hp, Wp, N) if epilogue == EPI_GLU_POOL else (NB, H, W, N)
-        out = torch.empty(shape, device=dev, dtype=torch.float32)
+        out = (torch.zeros if valid else torch.empty)(shape, device=dev, dtype=torch.float32)
+    if valid:
+        d.valid_h, d.valid_w = valid
     ntiles = NB * ((H + TH - 1) // TH) * (W // TW)
     stats = None
     if epilogue in (EPI_STATS, EPI_GLU_BWD, EPI_ADD_STATS2):
@@ -241,8 +245,9 @@ def igemm3s(inp, wtab, N, NB, H, W, taps, bias=None, epilogue=EPI_PLAIN):
     return out, stats
 
 
-def igemm3(inp, w3, N, NB, H, W, CIN, taps, bias=None, epilogue=EPI_PLAIN):
-    """3x3 conv forward / dgrad on the bf16 matrix cores with split-fp32 operands.  Returns (out, stats or None)."""
+def igemm3(inp, w3, N, NB, H, W, CIN, taps, bias=None, epilogue=EPI_PLAIN, valid=None):
+    """3x3 conv forward / dgrad on the bf16 matrix cores with split-fp32 operands.  Returns (out, stats or None).
+    valid: see igemm."""
     d = IgemmDesc()
     TH, TW = tile_for(W)
     NP = w3.shape[2]
@@ -253,7 +258,9 @@ def igemm3(inp, w3, N, NB, H, W, CIN, taps, bias=None, epilogue=EPI_PLAIN):
                NB * ((H + 2 * TH - 1) // (2 * TH)) * (W // TW) * (NP // 128) >= 1024) else 1
     TH *= rb
     dev = inp.device
-    out = torch.empty((NB, H, W, N), device=dev, dtype=torch.float32)
+    out = (torch.zeros if valid else torch.empty)((NB, H, W, N), device=dev, dtype=torch.float32)
+    if valid:
+        d.valid_h, d.valid_w = valid
     ntiles = NB * ((H + TH - 1) // TH) * (W // TW)
     stats = torch.empty((ntiles, 2, N), device=dev, dtype=torch.float32) if epilogue == EPI_STATS else None
     d.in_ = _dp(inp); d.w = w3.data_ptr(); d.bias = _p(bias); d.out = _p(out); d.stats = _p(stats)

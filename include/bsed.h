@@ -106,6 +106,10 @@ typedef struct BsedIgemmDesc {
   float drop_p;               /* dropout probability of the GLU epilogues (0 = off)                    */
   uint32_t rng_stream;        /* Philox stream id (layer id)                                           */
   uint64_t seed;
+  int valid_h, valid_w;       /* 0 = H, W.  Otherwise only output positions (h < valid_h, w < valid_w) are stored and
+                               * enter the STATS sums ("valid" convolutions computed on a padded grid: the stride-2
+                               * discriminator layers run as 2x2 stride-1 convolutions over space-to-depth input,
+                               * whose last row / column of the grid is not an output).  PLAIN / STATS epilogues. */
 } BsedIgemmDesc;
 
 int bsed_igemm(const BsedIgemmDesc* desc /*host*/, void* stream);
@@ -264,6 +268,21 @@ int bsed_glu_fwd3_auto_g(int C);
  * ConditionalDomainAdversarialLoss.forward (src/DA/cdan_frame.py:89-119).  The 3x3 / stride-2 / pad-0
  * convolutions run as im2col + bsed_igemm / bsed_wgrad; images are (N, H = time, W = feature, C).
  * ---------------------------------------------------------------------------------------------- */
+/* Space-to-depth glue of the direct stride-2 convolutions (csrc/disc.hip): a 3x3 / stride-2 / pad-0 convolution over
+ * A (Hi,Wi,C) equals a 2x2 / stride-1 convolution over X'[p][q][(a*2+b)*C + c] = A[2p+a][2q+b][c] (4C channels, taps
+ * (dp,dq) in {0,1}^2, weight slot (dp,dq,a,b) = W[2dp+a][2dq+b] or zero), which the implicit-GEMM kernels run without
+ * an im2col matrix.
+ *   bsed_s2d_fwd: X' (N,Hp,Wp,4C), Hp = ceil(Hi/2), Wp = ceil(Wi/2), from y (N,Ha,Wa,C) (allocated extent >= valid
+ *                 extent Hi x Wi) with BatchNorm apply + LeakyReLU(0.2) fused (scale/shift NULL: identity); pixels
+ *                 beyond Hi x Wi are zero.
+ *   bsed_s2d_bwd: g (N,Ha,Wa,C) = dX' gathered back * LeakyReLU'(y*scale+shift) on the valid extent, zero elsewhere, and
+ *                 per-block partial sums (sum g, sum g*y) for the BatchNorm backward: stats (bsed_s2d_num_blocks, 2, C). */
+int bsed_s2d_fwd(const float* y, const float* scale, const float* shift, float* xp, int N, int Ha, int Wa, int Hi, int Wi,
+                 int C, void* stream);
+int bsed_s2d_num_blocks(int N, int Ha, int Wa, int C);
+int bsed_s2d_bwd(const float* dxp, const float* y, const float* scale, const float* shift, float* g, float* stats, int N,
+                 int Ha, int Wa, int Hi, int Wi, int C, void* stream);
+
 /* col[(n,ho,wo)][(dw*3+dh)*CP + c] = leaky_relu_0.2(act*scale+shift) (identity when scale == NULL);
  * C == 1 writes 16 columns (9 taps + zeros).  Ho = (Hi-3)/2+1, Wo = (Wi-3)/2+1. */
 int bsed_im2col_s2(const float* act, const float* scale, const float* shift, float* col, int N, int Hi, int Wi,
