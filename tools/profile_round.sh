@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round profile on the GPU box: rocprofv3 kernel stats + PMC passes of the headline bench, bench lines of every mode.
+#   bash tools/profile_round.sh r02        (run from the repo root through gpurun; results under gpurun_out/<tag>_*)
+set -u
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="$R/bench.py --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o out --output-format csv -- python3 $BENCH --steps 10 --warmup 2 > $OUT/${TAG}_stats.log 2>&1
+echo "stats done"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c -d $OUT/${TAG}_pmc_$c -o out --output-format csv -- python3 $BENCH --no-kernel-timer --steps 2 --warmup 1 > $OUT/${TAG}_pmc_$c.log 2>&1
+  echo "pmc $c done"
+done
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/${TAG}_pmc_mfma -o out --output-format csv -- python3 $BENCH --no-kernel-timer --steps 2 --warmup 1 > $OUT/${TAG}_pmc_mfma.log 2>&1
+echo "pmc mfma done"
+cd $R
+python bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.log; echo "bench crnn done"
+python bench.py --steps 10 --no-cpu-baseline --mode mt > $OUT/${TAG}_bench_mt.json 2> $OUT/${TAG}_bench_mt.log
+python bench.py --steps 10 --no-cpu-baseline --mode ada > $OUT/${TAG}_bench_ada.json 2> $OUT/${TAG}_bench_ada.log
+python bench.py --steps 20 --no-cpu-baseline --mode cnn > $OUT/${TAG}_bench_cnn.json 2> $OUT/${TAG}_bench_cnn.log
+python bench.py --steps 10 --no-cpu-baseline --sr 32000 > $OUT/${TAG}_bench_sr32000.json 2> $OUT/${TAG}_bench_sr32000.log
+BSED_CONV_MODE=fp32 python bench.py --steps 6 --no-cpu-baseline > $OUT/${TAG}_bench_fp32_mode.json 2> $OUT/${TAG}_bench_fp32_mode.log
+python bench.py --steps 20 --no-cpu-baseline --batch 24 > $OUT/${TAG}_bench_batch24.json 2> $OUT/${TAG}_bench_batch24.log
+echo "bench lines done"
