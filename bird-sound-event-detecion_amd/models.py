@@ -172,6 +172,9 @@ class CRNN(_FlatModule):
         self.seed = 0
         self.fused_glu_bwd = True  # False = the unfused 4-launch chain (kept as a cross-check in the tests)
         self.glu3 = os.environ.get("BSED_GLU3", "1") != "0"  # split-fp32 GLU kernels (csrc/glu3.hip)
+        # GRU weight gradients of layer l on a side stream, beside the (latency-bound, half-chip) recurrence of layer l-1
+        self.overlap_rnn = os.environ.get("BSED_RNN_OVERLAP", "1") != "0"
+        self._side_stream = None
         # "bf16x3" (default): the 3x3 conv forward / data-gradient contractions and the GRU projection GEMMs run on the
         # bf16 matrix cores with split-fp32 operands (csrc/igemm3.hip; measured 5.5e-6 on the logits of the reference
         # config, 18x inside the 1e-4 bar).  "fp32": exact fp32 matrix cores everywhere (9.6e-7 on the logits).
@@ -356,25 +359,52 @@ class CRNN(_FlatModule):
             seq = out
         return seq, layers
 
+    def _side(self):
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        return self._side_stream
+
+    def _join_side(self):
+        """the current stream waits for the side stream's weight-gradient work (before anything reads the gradient arena)"""
+        if self._side_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._side_stream)
+
+    def _gru_param_grads(self, lay, l, prefix, dxp, dgh, pih, phh, B, T):
+        """bias and weight gradients of GRU layer l from its recurrence outputs (no consumer inside the backward pass)"""
+        nin, w_ih, w_hh, b_ih, b_hh = self._rnn_views(l, prefix)
+        g_wih, g_whh, g_bih, g_bhh = self._rnn_grads(l, prefix)
+        if pih is not None:  # the recurrence kernel already summed the bias gradients over time per batch row
+            ops.colsum(pih, pih.shape[0], 768, 768, g_bih)
+            ops.colsum(phh, phh.shape[0], 768, 768, g_bhh)
+        else:
+            ops.colsum(dxp, B * T, 768, 768, g_bih)
+            ops.colsum(dgh, B * T, 768, 768, g_bhh)
+        part, G, KP, NP = ops.wgrad(lay["inp"], dxp, 1, B * T, 1, nin, 768)
+        ops.reduce_partials(part, G, 1, KP, NP, nin, 768, g_wih, 0, 1, nin)
+        for dr in range(2):
+            part, G, KP, NP = ops.wgrad(lay["out"], dgh, B, T, 1, 128, 384, taps=((-1 if dr == 0 else 1, 0),),
+                                        in_pitch=256, dy_pitch=768, in_offset=dr * 128, dy_offset=dr * 384)
+            ops.reduce_partials(part, G, 1, KP, NP, 128, 384, g_whh, 0, 1, 128, dst_offset=dr * 384 * 128)
+
     def _gru_backward(self, layers, d, B, T, prefix):
-        """returns dL/d(input sequence) (B,T,nin of layer 0); parameter gradients accumulate into flat_grad"""
+        """returns dL/d(input sequence) (B,T,nin of layer 0); parameter gradients accumulate into flat_grad.  The
+        recurrence of a layer is latency-bound and occupies half the chip (one workgroup per 4 batch rows), and nothing
+        downstream needs a layer's WEIGHT gradients: they are enqueued on a side stream, where they run beside the next
+        layer's recurrence (and, for layer 0, beside the head of the CNN backward).  `_join_side` closes the fork."""
         for l in (1, 0):
             nin, w_ih, w_hh, b_ih, b_hh = self._rnn_views(l, prefix)
-            g_wih, g_whh, g_bih, g_bhh = self._rnn_grads(l, prefix)
             lay = layers[l]
             dxp, dgh, pih, phh = ops.gru_bwd(d, lay["out"], lay["gates"], w_hh, B, T, mode=self.conv_mode)
-            if pih is not None:  # the recurrence kernel already summed the bias gradients over time per batch row
-                ops.colsum(pih, pih.shape[0], 768, 768, g_bih)
-                ops.colsum(phh, phh.shape[0], 768, 768, g_bhh)
+            if self.overlap_rnn:
+                main, side = torch.cuda.current_stream(), self._side()
+                side.wait_stream(main)                      # dxp / dgh (and the zeroed gradient arena) are ready
+                with torch.cuda.stream(side):
+                    self._gru_param_grads(lay, l, prefix, dxp, dgh, pih, phh, B, T)
+                for t in (dxp, dgh, pih, phh, lay["inp"], lay["out"]):
+                    if t is not None:
+                        t.record_stream(side)               # the allocator must not recycle them under the side stream
             else:
-                ops.colsum(dxp, B * T, 768, 768, g_bih)
-                ops.colsum(dgh, B * T, 768, 768, g_bhh)
-            part, G, KP, NP = ops.wgrad(lay["inp"], dxp, 1, B * T, 1, nin, 768)
-            ops.reduce_partials(part, G, 1, KP, NP, nin, 768, g_wih, 0, 1, nin)
-            for dr in range(2):
-                part, G, KP, NP = ops.wgrad(lay["out"], dgh, B, T, 1, 128, 384, taps=((-1 if dr == 0 else 1, 0),),
-                                            in_pitch=256, dy_pitch=768, in_offset=dr * 128, dy_offset=dr * 384)
-                ops.reduce_partials(part, G, 1, KP, NP, 128, 384, g_whh, 0, 1, 128, dst_offset=dr * 384 * 128)
+                self._gru_param_grads(lay, l, prefix, dxp, dgh, pih, phh, B, T)
             if self.conv_mode == "bf16x3":
                 w3 = ops.pack_weight3(w_ih, 1, 768, nin, 0, nin, 1)
                 d, _ = ops.igemm3(dxp, w3, nin, 1, B * T, 1, 768, ((0, 0),))
@@ -507,8 +537,10 @@ class CRNN(_FlatModule):
 
     def _cnn_backward(self, ctx, dpool, on_early_grads=None):
         for i in range(len(self.nb_filters) - 1, -1, -1):
-            if on_early_grads is not None and i == min(self.TAIL_BLOCKS, len(self.nb_filters)) - 1:
-                on_early_grads()   # every gradient outside the first TAIL_BLOCKS blocks has been enqueued
+            if i == min(self.TAIL_BLOCKS, len(self.nb_filters)) - 1:
+                self._join_side()      # the GRU weight gradients (side stream) belong to the early segment
+                if on_early_grads is not None:
+                    on_early_grads()   # every gradient outside the first TAIL_BLOCKS blocks has been enqueued
             dpool = self._block_backward(ctx["blocks"][i], dpool, ctx["B"], ctx["seed"])
 
     def run_forward(self, x, save=True):
@@ -538,6 +570,7 @@ class CRNN(_FlatModule):
             d = ops.dropout(d, ctx["drop"], 200, ctx["seed"])
         d = self._gru_backward(ctx["layers"], d, B, T, "rnn")
         if not self.train_cnn:
+            self._join_side()
             if on_early_grads is not None:
                 on_early_grads()
             return
@@ -684,6 +717,7 @@ class CRNN_fpn(CRNN):
                 d = ops.dropout(d, drop, stream, seed)
             d_seq.append(self._gru_backward(layers, d, B, Tl, pfx))
         if not self.train_cnn:
+            self._join_side()
             if on_early_grads is not None:
                 on_early_grads()
             return

@@ -52,7 +52,7 @@ class KernelTimer:
 
     def __init__(self):
         self.records = {}  # key -> [flops_per_launch, [(start, end), ...], algorithmic_bytes_per_launch]
-        self._last, self._chain = None, False
+        self._last, self._chain = {}, False
 
     @staticmethod
     def prime(n=4096):
@@ -70,14 +70,15 @@ class KernelTimer:
         the start of launch i+1 (half the events of a start/end pair per launch: each event costs the GPU ~1.5 us).  A
         launch that follows anything other than a timed launch (the first of a step: host-side work in between) gets
         its own start event."""
-        s = self._last if self._chain else None
+        sid = L.stream().value                      # chains are per stream (side-stream launches overlap the main one)
+        s = self._last.get(sid) if self._chain else None
         if s is None:
             s = torch.cuda.Event(enable_timing=True)
             s.record()
         fn()
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        self._last, self._chain = e, True
+        self._last[sid], self._chain = e, True
         rec = self.records.setdefault(key, [flops, [], nbytes])
         rec[1].append((s, e))
 
@@ -338,7 +339,7 @@ _scratch = {}
 
 
 def stats_scratch(C, device):
-    key = (C, str(device))
+    key = (C, str(device), L.stream().value)   # one scratch per stream: launches of different streams may overlap
     s = _scratch.get(key)
     if s is None:
         n = L.lib().bsed_stats_scratch_bytes
