@@ -1198,8 +1198,12 @@ static int wgrad_prepare(const BsedWgradDesc* desc, WgradParams& P, size_t& smem
   P.PP = P.PW * P.PH;
   // input channels are contracted in chunks of CC per workgroup (grid.z): 64 for the 9-tap convolutions so that
   // two workgroups fit in a CU's LDS and one's tile load overlaps the other's MFMAs, 128 for the 1-tap forms
+  // (A/B knob: BSED_WGRAD3_1TAP_PIPE=1 gives the split-fp32 1-tap forms the multi-tap geometry -- 64-channel chunks, an
+  //  80 KB tile -- so that the producer / consumer kernel with its two tile buffers can take them)
+  static const bool onetap_pipe = getenv("BSED_WGRAD3_1TAP_PIPE") && getenv("BSED_WGRAD3_1TAP_PIPE")[0] == '1';
+  const bool wide1 = d.ntaps == 1 && !(mode3 && onetap_pipe);
   P.CC = 32;
-  for (int cand = (d.ntaps == 1 ? 128 : 64); cand >= 32; cand >>= 1)
+  for (int cand = (wide1 ? 128 : 64); cand >= 32; cand >>= 1)
     if (d.CINP % cand == 0) { P.CC = cand; break; }
   // tall narrow tiles (W = 2: 66 x 4 halo patch) would leave a single workgroup per CU with 64-channel chunks
   if (mode3 && d.ntaps > 1 && P.CC > 32 && (size_t)P.PP * P.CC * 4 + (size_t)W3_DY_BYTES > 80 * 1024) P.CC = 32;
@@ -1219,7 +1223,7 @@ static int wgrad_prepare(const BsedWgradDesc* desc, WgradParams& P, size_t& smem
   for (int cand = 4; cand >= 2; cand >>= 1) {
     const size_t need = mode3 ? (size_t)P.dy_off * 4 + (size_t)W3_DY_BYTES * cand
                               : ((size_t)P.dy_off + IG_TILE_M * 32 * cand) * sizeof(float);
-    const size_t budget = d.ntaps == 1 ? 160 * 1024 : 80 * 1024;
+    const size_t budget = wide1 ? 160 * 1024 : 80 * 1024;
     const int tap_items = P.pack2 ? (d.ntaps + 1) / 2 : d.ntaps;
     if (d.NP % (32 * cand) == 0 && tap_items * P.nct * cand <= 36 && need <= budget) { P.ntw = cand; break; }
   }
@@ -1345,7 +1349,11 @@ static int launch_wgrad3p(const WgradParams& P, dim3 grid, size_t smem, hipStrea
 // its register arrays; everything else (1-tap forms, tall narrow patches) stays on wgrad3_kernel
 static bool wgrad3_pipelined(const WgradParams& P, size_t smem) {
   const int nitems = (P.pack2 ? (P.d.ntaps + 1) / 2 : P.d.ntaps) * P.nct * P.ntw;
-  return P.d.ntaps > 1 && P.d.H < 16384 && P.d.W < 16384 && 2 * smem <= 160 * 1024 && 4 % (P.nct * P.ntw) == 0 && nitems > 8 && nitems <= 36 &&
+  static const int pipe_min = getenv("BSED_WGRAD3_PIPE_MIN") ? atoi(getenv("BSED_WGRAD3_PIPE_MIN")) : 8;  // A/B knob
+  static const bool onetap_pipe = getenv("BSED_WGRAD3_1TAP_PIPE") && getenv("BSED_WGRAD3_1TAP_PIPE")[0] == '1';
+  if (P.d.ntaps == 1 && !onetap_pipe) return false;
+  return nitems > (P.d.ntaps == 1 ? 3 : pipe_min) &&
+         P.d.H < 16384 && P.d.W < 16384 && 2 * smem <= 160 * 1024 && 4 % (P.nct * P.ntw) == 0 && nitems <= 36 &&
          P.PP * (P.CC / 4) <= W3P_UX * 256 && IG_TILE_M * 8 * P.ntw <= W3P_UD * 256 && !getenv("BSED_WGRAD3_NOPIPE");
 }
 
@@ -1371,7 +1379,7 @@ extern "C" int bsed_wgrad3_variant(const BsedWgradDesc* desc) {
   if (wgrad_prepare(desc, P, smem, gyz, 1) != BSED_OK) return -1;
   const int v = wgrad_variant(P);
   if (wgrad3_pipelined(P, smem)) {  // NW field 1 = wgrad3p_kernel<MAXS, GEO>, GEO in bits 8..11
-    const int maxs = v / 16, g = getenv("BSED_WGRAD3_NOGEO") ? 0 : wgrad3p_geo(P);
+    const int maxs = v / 16 <= 3 ? 3 : (v / 16 <= 5 ? 5 : 9), g = getenv("BSED_WGRAD3_NOGEO") ? 0 : wgrad3p_geo(P);
     const bool built = (maxs == 9 && (g == 1 || g == 2)) || (maxs == 5 && g >= 3 && g <= 5);
     return maxs * 16 + 1 + ((built ? g : 0) << 8);
   }
@@ -1391,8 +1399,8 @@ extern "C" int bsed_wgrad3(const BsedWgradDesc* desc, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int v = wgrad_variant(P), maxs = v / 16, nw = v % 16;
   if (wgrad3_pipelined(P, smem)) {
-    if (maxs == 3) return launch_wgrad3p<3>(P, grid, smem, s);
-    if (maxs == 5) return launch_wgrad3p<5>(P, grid, smem, s);
+    if (maxs <= 3) return launch_wgrad3p<3>(P, grid, smem, s);
+    if (maxs <= 5) return launch_wgrad3p<5>(P, grid, smem, s);
     return launch_wgrad3p<9>(P, grid, smem, s);
   }
   if (nw == 8) {

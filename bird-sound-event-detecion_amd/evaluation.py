@@ -141,9 +141,12 @@ def get_predictions(model, dataloader, decoder, pooling_time_ratio=1, thresholds
                                     "annotation/<name>.txt next to wav/<name>.npy)")
         df = pd.read_csv(path, sep="\t")
         df["filename"] = name
-        gts.append(df)
+        if len(df):
+            gts.append(df)
     if gts:
         groundtruth_df = pd.concat(gts, ignore_index=True)
+    elif seen:
+        groundtruth_df = pd.DataFrame(columns=["onset", "offset", "event_label", "filename"])
 
     if save_predictions is not None:
         if isinstance(save_predictions, str):

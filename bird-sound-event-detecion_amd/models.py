@@ -172,8 +172,11 @@ class CRNN(_FlatModule):
         self.seed = 0
         self.fused_glu_bwd = True  # False = the unfused 4-launch chain (kept as a cross-check in the tests)
         self.glu3 = os.environ.get("BSED_GLU3", "1") != "0"  # split-fp32 GLU kernels (csrc/glu3.hip)
-        # GRU weight gradients of layer l on a side stream, beside the (latency-bound, half-chip) recurrence of layer l-1
-        self.overlap_rnn = os.environ.get("BSED_RNN_OVERLAP", "1") != "0"
+        # BSED_RNN_OVERLAP=1: GRU weight gradients of layer l on a side stream, beside the (latency-bound, half-chip)
+        # recurrence of layer l-1: -0.15 .. -0.3 ms per step at B = 256.  Off by default: the overlapped 1-tap weight
+        # gradients are stretched by the recurrence they share the chip with, which would make per-kernel durations
+        # (bench.py's roofline object, rocprof summaries) describe the overlap rather than the kernels.
+        self.overlap_rnn = os.environ.get("BSED_RNN_OVERLAP", "0") == "1"
         self._side_stream = None
         # "bf16x3" (default): the 3x3 conv forward / data-gradient contractions and the GRU projection GEMMs run on the
         # bf16 matrix cores with split-fp32 operands (csrc/igemm3.hip; measured 5.5e-6 on the logits of the reference

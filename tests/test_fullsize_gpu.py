@@ -107,13 +107,15 @@ def test_from_waveform_step_is_the_composition_of_mel_and_crnn_at_full_size():
 def test_train_step_is_bitwise_repeatable_at_full_size():
     """Two runs from the same state give bit-identical gradients (dropout on): every reduction in the path is ordered
     (partial slabs + fixed-order sums, no float atomics on the CRNN path).  This check found a VALU -> MFMA SrcC
-    hand-off hazard (one stale element per ~10 runs) that no tolerance-based test could see."""
+    hand-off hazard (one stale element per ~10 runs) that no tolerance-based test could see.  The third run puts the
+    GRU weight gradients on the side stream (BSED_RNN_OVERLAP): same bits."""
     from bsed_amd.engine import FlatAdam, SEDTrainer
     x = torch.from_numpy(seeded.db_like_input(12, B, T)).cuda()
     y = torch.from_numpy(seeded.strong_targets(13, B, T // 4)).cuda()
     grads = []
     for rep in range(3):
         crnn, pred = _models(0.5)
+        crnn.overlap_rnn = rep == 2
         crnn.set_seed(5)
         tr = SEDTrainer(crnn, pred, optimizer=FlatAdam([crnn, pred], lr=1e-3), seed=7)
         junk = torch.empty((rep + 1) << 20, device="cuda")  # shift the allocator between repetitions
