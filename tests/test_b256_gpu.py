@@ -138,3 +138,48 @@ def test_from_waveform_step_at_b256_is_the_composition(batch):
         res.append((SEDTrainer.loss_value(out), crnn.flat_grad.clone()))
     assert np.isfinite(res[0][0]) and res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1])
+
+
+def test_mean_teacher_and_adversarial_steps_at_bench_shape_are_repeatable(batch):
+    """BASELINE configs[3] / [4] as bench.py runs them (--mode mt / ada): 128 synthetic + 128 real clips of 865 frames,
+    dropout 0.5.  Two runs from the same state: identical losses and gradient arenas, bit for bit (student, predictor
+    and discriminator gradients share one arena); the EMA teacher moves by (1 - alpha_t) of the gap; the adversarial
+    step's domain loss starts at the discriminator's chance level and its gradient reaches the CRNN."""
+    from bsed_amd.disc import Clip_Discriminator, ConditionalDomainAdversarialLoss
+    from bsed_amd.engine import FlatAdam, FlatSGD, SEDTrainer
+    x, y = batch
+    h = B // 2
+    xs, ys, xr = x[:h].contiguous(), y[:h].contiguous(), x[h:].contiguous()
+    yw = y[h:].max(1)[0].contiguous()
+    xe = (xr + 0.5).contiguous()
+    ocrnn, opred = _oracle_pair(65)
+    # ---- mean teacher
+    runs = []
+    for rep in range(2):
+        crnn, pred = _product_pair(ocrnn, opred, 0.5)
+        ema_c, ema_p = _product_pair(ocrnn, opred, 0.5)
+        tr = SEDTrainer(crnn, pred, ema_c, ema_p, optimizer=FlatAdam([crnn, pred], lr=1e-3), seed=9)
+        before = crnn.flat.clone()
+        out = tr.train_step(xs, ys, xr, yw, xe)
+        runs.append((SEDTrainer.loss_value(out), tr.arena.flat.clone(), crnn.flat.clone(), ema_c.flat.clone()))
+        want = 0.5 * before + 0.5 * crnn.flat        # alpha = min(1 - 1/(1+1), 0.999) = 0.5 at global step 1
+        assert float((ema_c.flat - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-9
+    assert np.isfinite(runs[0][0]) and runs[0][0] == runs[1][0]
+    for i in (1, 2, 3):
+        assert torch.equal(runs[0][i], runs[1][i]), i
+    # ---- domain adversarial
+    runs = []
+    for rep in range(2):
+        crnn, pred = _product_pair(ocrnn, opred, 0.5)
+        torch.manual_seed(3)
+        disc = Clip_Discriminator()
+        cdan = ConditionalDomainAdversarialLoss(disc)
+        cdan.iter_num = 500
+        tr = SEDTrainer(crnn, pred, optimizer=FlatSGD([crnn, pred], lr=1e-3, momentum=0.9, weight_decay=1e-4),
+                        domain_loss=cdan, optimizer_d=FlatSGD([disc], lr=1e-4, momentum=0.9, weight_decay=1e-4), seed=9)
+        out = tr.train_step(xs, ys, xr, None)
+        runs.append((SEDTrainer.loss_value(out), float(out["domain"]), tr.arena.flat.clone()))
+        assert tr.arena.flat.numel() == crnn.flat.numel() + pred.flat.numel() + disc.flat.numel()
+        assert float(disc.flat_grad.abs().max()) > 0 and bool(torch.isfinite(tr.arena.flat).all())
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][2], runs[1][2])
+    assert 0.3 < runs[0][1] < 1.5                     # BCE of an untrained discriminator: around log 2
