@@ -165,8 +165,8 @@ def kernel_roofline(name, launches, total_ms, flops_total, bytes_total):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default 256; 64 for --mode cnn)")
     ap.add_argument("--sr", type=int, default=22050, help="22050 = BASELINE measurement config, 32000 = reference config")
     ap.add_argument("--seconds", type=float, default=10.0)

@@ -1,7 +1,10 @@
 """Checkpoint dictionary of the reference (src/main_baseline.py:895-971,1040-1074): same keys, so files written by
 either side load in the other ("model", "model_p", ["model_d"], ["model_ema", "model_p_ema"], "optimizer", ...,
-"pooling_time_ratio", "many_hot_encoder", "median_window", "epoch").  State dicts are moved to the CPU on save;
-the "cnn." / "cnn.cnn." key quirk of reference checkpoints is absorbed by CRNN.load_state_dict."""
+"pooling_time_ratio", "many_hot_encoder", "median_window", "epoch").  Model state dicts are moved to the CPU on save;
+the "cnn." / "cnn.cnn." key quirk of reference checkpoints is absorbed by CRNN.load_state_dict.  The "optimizer" /
+"optimizer_d" entries hold FlatAdam / FlatSGD state in torch.optim's own format (per-parameter exp_avg / exp_avg_sq /
+momentum_buffer in the reference's parameter order, CPU tensors), so ``torch.optim.Adam(...).load_state_dict(
+state["optimizer"]["state_dict"])`` of the reference (src/main_baseline.py:874) accepts them and vice versa."""
 import torch
 
 
