@@ -301,6 +301,127 @@ __global__ void disc_head_kernel(const float* __restrict__ y5, const float* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Frame-level discriminator glue (reference Frame_Discriminator, src/models/CRNN_GRL.py:116-140: three per-frame Linear
+// layers 256 -> 128 -> 32 -> 1 with LeakyReLU(0.2) + Dropout between them and a sigmoid at the end).  The two wide
+// layers are 1-tap contractions on the implicit-GEMM kernels; this file holds the elementwise stages and the 32 -> 1 head.
+//   leaky_dropout_fwd/bwd : out = leaky(a) * mask,  d_a = d_out * mask * leaky'(a)   (mask: counter hash, regenerated)
+//   frame_head_fwd        : d[m] = sigmoid(sum_k x[m][k] w[k] + b)
+//   frame_head_bwd        : dz = d_out * d (1 - d);  dx[m][k] = dz w[k];  per-block partials of dw[k] = sum dz x[m][k], db
+// ---------------------------------------------------------------------------------------------
+__global__ void leaky_dropout_fwd_kernel(const float* __restrict__ a, float* __restrict__ out, long n4, float slope,
+                                         float drop_p, uint32_t rng_stream, uint64_t seed) {
+  const uint32_t dkey = drop_key(rng_stream, seed), dthr = drop_threshold(drop_p);
+  const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(a)[i];
+    float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      r[k] = (r[k] > 0.f ? r[k] : slope * r[k]) * (drop_p > 0.f ? drop_mul((uint64_t)(4 * i + k), dkey, dthr, dscale) : 1.f);
+    reinterpret_cast<float4*>(out)[i] = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+__global__ void leaky_dropout_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ a,
+                                         float* __restrict__ d_a, long n4, float slope, float drop_p, uint32_t rng_stream,
+                                         uint64_t seed) {
+  const uint32_t dkey = drop_key(rng_stream, seed), dthr = drop_threshold(drop_p);
+  const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 g = reinterpret_cast<const float4*>(d_out)[i];
+    const float4 v = reinterpret_cast<const float4*>(a)[i];
+    const float gv[4] = {g.x, g.y, g.z, g.w}, av[4] = {v.x, v.y, v.z, v.w};
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      r[k] = gv[k] * (av[k] > 0.f ? 1.f : slope) * (drop_p > 0.f ? drop_mul((uint64_t)(4 * i + k), dkey, dthr, dscale) : 1.f);
+    reinterpret_cast<float4*>(d_a)[i] = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+#define FH_K 32
+__global__ __launch_bounds__(256) void frame_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, float* __restrict__ d, long M) {
+  const long m = (long)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float z = b[0];
+#pragma unroll
+  for (int k = 0; k < FH_K; k += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(x + m * FH_K + k);
+    z = fmaf(v.x, w[k], fmaf(v.y, w[k + 1], fmaf(v.z, w[k + 2], fmaf(v.w, w[k + 3], z))));
+  }
+  d[m] = sigmoidf_(z);
+}
+
+__global__ __launch_bounds__(256) void frame_head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ d, const float* __restrict__ d_out,
+                                                             float* __restrict__ dx, float* __restrict__ part /*(G,2,32)*/,
+                                                             long M) {
+  __shared__ float red[256 * (FH_K + 1)];
+  const int tid = threadIdx.x;
+  float acc[FH_K], accb = 0.f;
+#pragma unroll
+  for (int k = 0; k < FH_K; ++k) acc[k] = 0.f;
+  for (long m = (long)blockIdx.x * 256 + tid; m < M; m += (long)gridDim.x * 256) {
+    const float s = d[m];
+    const float dz = d_out[m] * s * (1.f - s);
+    accb += dz;
+#pragma unroll
+    for (int k = 0; k < FH_K; k += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(x + m * FH_K + k);
+      acc[k] = fmaf(dz, v.x, acc[k]); acc[k + 1] = fmaf(dz, v.y, acc[k + 1]);
+      acc[k + 2] = fmaf(dz, v.z, acc[k + 2]); acc[k + 3] = fmaf(dz, v.w, acc[k + 3]);
+      *reinterpret_cast<float4*>(dx + m * FH_K + k) = make_float4(dz * w[k], dz * w[k + 1], dz * w[k + 2], dz * w[k + 3]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < FH_K; ++k) red[tid * (FH_K + 1) + k] = acc[k];
+  red[tid * (FH_K + 1) + FH_K] = accb;
+  __syncthreads();
+  if (tid <= FH_K) {
+    float s = 0.f;
+    for (int t = 0; t < 256; ++t) s += red[t * (FH_K + 1) + tid];   // fixed order
+    if (tid < FH_K) { part[((size_t)blockIdx.x * 2 + 0) * FH_K + tid] = s; part[((size_t)blockIdx.x * 2 + 1) * FH_K + tid] = 0.f; }
+    else part[((size_t)blockIdx.x * 2 + 1) * FH_K] = s;             // db rides in row 1, column 0
+  }
+}
+
+extern "C" int bsed_leaky_dropout_fwd(const float* a, float* out, long n, float slope, float drop_p, uint32_t rng_stream,
+                                      uint64_t seed, void* stream) {
+  BSED_CHECK_ARG(a && out && n > 0 && n % 4 == 0 && drop_p >= 0.f && drop_p < 1.f, "bsed_leaky_dropout_fwd: bad argument");
+  hipLaunchKernelGGL(leaky_dropout_fwd_kernel, dim3((unsigned)std::min<long>(ceil_div(n / 4, 256), 16384)), dim3(256), 0,
+                     (hipStream_t)stream, a, out, n / 4, slope, drop_p, rng_stream, seed);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_leaky_dropout_bwd(const float* d_out, const float* a, float* d_a, long n, float slope, float drop_p,
+                                      uint32_t rng_stream, uint64_t seed, void* stream) {
+  BSED_CHECK_ARG(d_out && a && d_a && n > 0 && n % 4 == 0 && drop_p >= 0.f && drop_p < 1.f, "bsed_leaky_dropout_bwd: bad argument");
+  hipLaunchKernelGGL(leaky_dropout_bwd_kernel, dim3((unsigned)std::min<long>(ceil_div(n / 4, 256), 16384)), dim3(256), 0,
+                     (hipStream_t)stream, d_out, a, d_a, n / 4, slope, drop_p, rng_stream, seed);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_frame_head_fwd(const float* x, const float* w, const float* b, float* d, long M, int K, void* stream) {
+  BSED_CHECK_ARG(x && w && b && d && M > 0, "bsed_frame_head_fwd: bad argument");
+  BSED_CHECK_ARG(K == FH_K, "bsed_frame_head_fwd: built for K = %d (got %d)", FH_K, K);
+  hipLaunchKernelGGL(frame_head_fwd_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream, x, w, b, d, M);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_frame_head_bwd(const float* x, const float* w, const float* d, const float* d_out, float* dx,
+                                   float* part, int G, long M, int K, void* stream) {
+  BSED_CHECK_ARG(x && w && d && d_out && dx && part && M > 0 && G > 0 && G <= 4096, "bsed_frame_head_bwd: bad argument");
+  BSED_CHECK_ARG(K == FH_K, "bsed_frame_head_bwd: built for K = %d (got %d)", FH_K, K);
+  hipLaunchKernelGGL(frame_head_bwd_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, x, w, d, d_out, dx, part, M);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
 extern "C" int bsed_im2col_s2(const float* act, const float* scale, const float* shift, float* col, int N, int Hi, int Wi,
                               int C, int CP, void* stream) {
   BSED_CHECK_ARG(act && col && N > 0 && Hi >= 3 && Wi >= 3, "bsed_im2col_s2: bad argument");

@@ -309,6 +309,128 @@ class Clip_Discriminator(_FlatModule):
         return d.view(-1, 1)
 
 
+class Frame_Discriminator(_FlatModule):
+    """Drop-in for the reference's frame-level discriminator (src/models/CRNN_GRL.py:116-140):
+    ``d = sigmoid(L3(drop(leaky(L2(drop(leaky(L1(x))))))))`` per frame, (N,T,256) -> (N,T,1), LeakyReLU(0.2), the two wide
+    layers as 1-tap contractions on the implicit-GEMM kernels, the 32 -> 1 head and the elementwise stages in
+    csrc/disc.hip.  ``disc(x)`` is differentiable (autograd bridge); ``run_forward`` / ``run_backward`` are the explicit
+    pair.  The reference never gives this module a runnable loss (main_baseline.py:789-796 pairs it with a loss whose
+    labels are per clip: torch's BCE rejects the shapes) -- parity is the module's own forward and
+    backward."""
+    SLOPE = 0.2
+
+    def __init__(self, input_dim=None, dropout=0, device="cuda"):
+        super().__init__()
+        L._require_gpu()
+        self.dropout_p = float(dropout)
+        self.seed = 0
+        import os
+        self.conv_mode = os.environ.get("BSED_DISC_MODE", "fp32")
+        pspecs = [("dense_d_1.weight", (128, 256)), ("dense_d_1.bias", (128,)),
+                  ("dense_d_2.weight", (32, 128)), ("dense_d_2.bias", (32,)),
+                  ("dense_d_3.weight", (1, 32)), ("dense_d_3.bias", (1,))]
+        self._build(pspecs, [], device)
+        self._init_order = [("dense_d_1", "linear"), ("dense_d_2", "linear"), ("dense_d_3", "linear")]
+        self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self):
+        for name, p in self.named_parameters():
+            w = p if name.endswith("weight") else self.P(name[:-4] + "weight")
+            b = 1 / math.sqrt(w.shape[1])
+            p.uniform_(-b, b)
+
+    def set_seed(self, seed):
+        self.seed = int(seed)
+
+    def _linear(self, x, name, M, K, N):
+        w, b = self.P(name + ".weight"), self.P(name + ".bias")
+        if self.conv_mode == "bf16x3":
+            return ops.igemm3(x, ops.pack_weight3(w, 1, K, N, 0, 1, K), N, 1, M, 1, K, ((0, 0),), bias=b)[0]
+        return ops.igemm(x, ops.pack_weight(w, 1, K, N, 0, 1, K), N, 1, M, 1, K, bias=b)[0]
+
+    def _linear_bwd(self, x, dy, name, M, K, N):
+        """accumulates dW, db of y = x W^T + b; returns dL/dx (M,K)"""
+        w, b = self.P(name + ".weight"), self.P(name + ".bias")
+        ops.colsum(dy, M, N, N, b.grad)
+        part, G, KP, NP = ops.wgrad(x, dy, 1, M, 1, K, N)
+        ops.reduce_partials(part, G, 1, KP, NP, K, N, w.grad, 0, 1, K)
+        if self.conv_mode == "bf16x3":
+            return ops.igemm3(dy, ops.pack_weight3(w, 1, N, K, 0, K, 1), K, 1, M, 1, N, ((0, 0),))[0]
+        return ops.igemm(dy, ops.pack_weight(w, 1, N, K, 0, K, 1), K, 1, M, 1, N)[0]
+
+    def _act(self, a, stream_id, drop):
+        out = torch.empty_like(a)
+        L.call("bsed_leaky_dropout_fwd", L.ptr(a), L.ptr(out), ctypes.c_long(a.numel()), ctypes.c_float(self.SLOPE),
+               ctypes.c_float(drop), ctypes.c_uint32(stream_id), ctypes.c_uint64(self.seed), L.stream())
+        return out
+
+    def _act_bwd(self, d_out, a, stream_id, drop, seed):
+        d_a = torch.empty_like(a)
+        L.call("bsed_leaky_dropout_bwd", L.ptr(d_out), L.ptr(a), L.ptr(d_a), ctypes.c_long(a.numel()),
+               ctypes.c_float(self.SLOPE), ctypes.c_float(drop), ctypes.c_uint32(stream_id), ctypes.c_uint64(seed), L.stream())
+        return d_a
+
+    def run_forward(self, x, save=True):
+        x = x.contiguous().float()
+        N, T, F = x.shape
+        if F != 256:
+            raise L.BsedError(f"Frame_Discriminator takes 256-feature encodings, got {F}")
+        M = N * T
+        drop = self.dropout_p if self.training else 0.0
+        x2d = x.view(M, 256)
+        a1 = self._linear(x2d, "dense_d_1", M, 256, 128).view(M, 128)
+        h1 = self._act(a1, 401, drop)
+        a2 = self._linear(h1, "dense_d_2", M, 128, 32).view(M, 32)
+        h2 = self._act(a2, 402, drop)
+        d = torch.empty((M,), device=x.device, dtype=torch.float32)
+        w3, b3 = self.P("dense_d_3.weight"), self.P("dense_d_3.bias")
+        L.call("bsed_frame_head_fwd", L.ptr(h2), ctypes.c_void_p(w3.data_ptr()), ctypes.c_void_p(b3.data_ptr()), L.ptr(d),
+               ctypes.c_long(M), _i(32), L.stream())
+        ctx = dict(x=x2d, a1=a1, h1=h1, a2=a2, h2=h2, d=d, M=M, drop=drop, seed=self.seed, shape=(N, T)) if save else None
+        return d.view(N, T, 1), ctx
+
+    def run_backward(self, ctx, d_out):
+        """d_out: dL/d(domain_out) (N,T,1).  Accumulates parameter gradients, returns dL/dx (N,T,256)."""
+        M = ctx["M"]
+        w3, b3 = self.P("dense_d_3.weight"), self.P("dense_d_3.bias")
+        G = int(min(1024, max(1, M // 256)))
+        dh2 = torch.empty((M, 32), device=d_out.device, dtype=torch.float32)
+        part = torch.empty((G, 2, 32), device=d_out.device, dtype=torch.float32)
+        L.call("bsed_frame_head_bwd", L.ptr(ctx["h2"]), ctypes.c_void_p(w3.data_ptr()), L.ptr(ctx["d"]),
+               L.ptr(d_out.contiguous().view(M)), L.ptr(dh2), L.ptr(part), _i(G), ctypes.c_long(M), _i(32), L.stream())
+        ops.stats_to_grad(part, 32, 0, w3.grad)
+        tmp = torch.zeros(32, device=d_out.device, dtype=torch.float32)
+        ops.stats_to_grad(part, 32, 1, tmp)
+        ops.axpy(b3.grad, tmp[:1])
+        da2 = self._act_bwd(dh2, ctx["a2"], 402, ctx["drop"], ctx["seed"])
+        dh1 = self._linear_bwd(ctx["h1"], da2, "dense_d_2", M, 128, 32).view(M, 128)
+        da1 = self._act_bwd(dh1, ctx["a1"], 401, ctx["drop"], ctx["seed"])
+        dx = self._linear_bwd(ctx["x"], da1, "dense_d_1", M, 256, 128)
+        N, T = ctx["shape"]
+        return dx.view(N, T, 256)
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or self.training):
+            return _FrameDFunction.apply(x, self, self.P("dense_d_1.weight"))
+        return self.run_forward(x, save=False)[0]
+
+
+class _FrameDFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module, flat):
+        d, c = module.run_forward(x, save=True)
+        ctx.module, ctx.c = module, c
+        return d
+
+    @staticmethod
+    def backward(ctx, d_out):
+        ctx.module._attach_grads()
+        dx = ctx.module.run_backward(ctx.c, d_out)
+        ctx.c = None
+        return dx, None, None
+
+
 class ConditionalDomainAdversarialLoss(nn.Module):
     """Same call as the reference: ``loss = cdan(g_s, f_s, g_t, f_t)`` (g_* are accepted and, as in the reference's
     active code path, do not enter the result).  ``forward`` returns the loss as a device scalar and stores what
@@ -319,6 +441,12 @@ class ConditionalDomainAdversarialLoss(nn.Module):
         super().__init__()
         if entropy_conditioning or randomized or reduction != "mean":
             raise NotImplementedError("only the reference's active configuration (plain BCE, mean) is built")
+        if isinstance(domain_discriminator, Frame_Discriminator):
+            # the reference's own pairing (main_baseline.py:789-796) dies in F.binary_cross_entropy: (N,T,1) predictions
+            # against (N,) clip labels (src/DA/cdan_frame.py:99-103,119); same error behaviour here
+            raise ValueError("Using a target size (torch.Size([N])) that is different to the input size "
+                             "(torch.Size([N, T, 1])) is deprecated. Please ensure they have the same size. "
+                             "[ConditionalDomainAdversarialLoss labels clips; Frame_Discriminator scores frames]")
         self.domain_discriminator = domain_discriminator
         self.iter_num = 0
         self.alpha, self.lo, self.hi, self.max_iters = 1.0, 0.0, 1.0, 1000.0

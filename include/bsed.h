@@ -268,6 +268,19 @@ int bsed_glu_fwd3_auto_g(int C);
  * ConditionalDomainAdversarialLoss.forward (src/DA/cdan_frame.py:89-119).  The 3x3 / stride-2 / pad-0
  * convolutions run as im2col + bsed_igemm / bsed_wgrad; images are (N, H = time, W = feature, C).
  * ---------------------------------------------------------------------------------------------- */
+/* Frame-level discriminator glue (csrc/disc.hip; reference Frame_Discriminator, src/models/CRNN_GRL.py:116-140).
+ *   bsed_leaky_dropout_fwd/bwd: out = LeakyReLU_slope(a) * dropout mask; d_a = d_out * mask * LeakyReLU'(a) (n % 4 == 0;
+ *     the mask is a counter hash of (seed, rng_stream, element index), regenerated in backward);
+ *   bsed_frame_head_fwd: d (M) = sigmoid(x (M,32) . w (32) + b);
+ *   bsed_frame_head_bwd: dx (M,32) and part (G,2,32): row 0 = partial dw, row 1 column 0 = partial db (sum over G). */
+int bsed_leaky_dropout_fwd(const float* a, float* out, long n, float slope, float drop_p, uint32_t rng_stream,
+                           uint64_t seed, void* stream);
+int bsed_leaky_dropout_bwd(const float* d_out, const float* a, float* d_a, long n, float slope, float drop_p,
+                           uint32_t rng_stream, uint64_t seed, void* stream);
+int bsed_frame_head_fwd(const float* x, const float* w, const float* b, float* d, long M, int K, void* stream);
+int bsed_frame_head_bwd(const float* x, const float* w, const float* d, const float* d_out, float* dx, float* part, int G,
+                        long M, int K, void* stream);
+
 /* Space-to-depth glue of the direct stride-2 convolutions (csrc/disc.hip): a 3x3 / stride-2 / pad-0 convolution over
  * A (Hi,Wi,C) equals a 2x2 / stride-1 convolution over X'[p][q][(a*2+b)*C + c] = A[2p+a][2q+b][c] (4C channels, taps
  * (dp,dq) in {0,1}^2, weight slot (dp,dq,a,b) = W[2dp+a][2dq+b] or zero), which the implicit-GEMM kernels run without

@@ -11,6 +11,7 @@ can exchange weights; pinned by ``tests/golden/crnn_*.npz`` (oracle/gen_golden.p
   * Predictor            <- src/models/CRNN_GRL.py:430-460
   * CRNN_pred            <- src/models/CRNN_GRL.py:206-290 (CNN-only tagger, BASELINE configs[1])
   * Clip_Discriminator   <- src/models/CRNN_GRL.py:16-53
+  * Frame_Discriminator  <- src/models/CRNN_GRL.py:116-140
   * weights_init         <- src/utilities/utils.py:40-63
   * update_ema_variables <- src/main_baseline.py:91-105
   * ramps                <- src/utilities/ramps.py:4-30
@@ -226,6 +227,22 @@ class Clip_Discriminator(nn.Module):
             x = F.leaky_relu(getattr(self, f"bn_{i}")(getattr(self, f"conv_{i}")(x)), 0.2)
         x = F.adaptive_avg_pool2d(x, (2, 1)).flatten(1)
         return torch.sigmoid(self.dense_d(x))
+
+
+class Frame_Discriminator(nn.Module):
+    """reference src/models/CRNN_GRL.py:116-140: per-frame 256 -> 128 -> 32 -> 1, LeakyReLU(0.2) + Dropout, sigmoid"""
+
+    def __init__(self, input_dim=None, dropout=0):
+        super().__init__()
+        self.dense_d_1 = nn.Linear(256, 128)
+        self.dense_d_2 = nn.Linear(128, 32)
+        self.dense_d_3 = nn.Linear(32, 1)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        x = self.dropout(F.leaky_relu(self.dense_d_1(x), 0.2))
+        x = self.dropout(F.leaky_relu(self.dense_d_2(x), 0.2))
+        return torch.sigmoid(self.dense_d_3(x))
 
 
 def weights_init(m):

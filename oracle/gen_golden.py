@@ -368,6 +368,29 @@ def fpn_init_case():
     print("wrote weights_init_fpn.json", len(stats))
 
 
+def frame_d_case():
+    """the reference's Frame_Discriminator (models/CRNN_GRL.py:116-140): forward and, for a fixed upstream gradient, the
+    gradients of every parameter and of the input (the reference defines no runnable loss for it)"""
+    from models.CRNN_GRL import Frame_Discriminator
+    seed, N, T = 83, 3, 157
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((N, T, 256)).astype(np.float32)
+    m = Frame_Discriminator(input_dim=256, dropout=0)
+    vals = seeded.load_seeded(m, seed + 1)
+    m.train()
+    xt = t(x).requires_grad_()
+    d = m(xt)
+    up = (torch.cos(torch.arange(d.numel(), dtype=torch.float32)).view_as(d) * 0.3)
+    (d * up).sum().backward()
+    g = {"meta": np.array([N, T, seed]), "weight_checksum": np.array([seeded.checksum(vals)]), "out": d.detach().numpy(),
+         "dx": xt.grad.numpy()[:, ::7, ::5].copy(), "dx_norm": np.array(float(xt.grad.norm())),
+         "state_names": np.array(list(m.state_dict().keys()))}
+    for k, p in m.named_parameters():
+        g["grad/" + k] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "frame_d.npz"), **g)
+    print("wrote frame_d.npz", {k: getattr(v, "shape", None) for k, v in g.items()})
+
+
 def cnn_pred_case():
     """BASELINE configs[1] (CNN-only tagging forward): the reference's CRNN_pred (models/CRNN_GRL.py:206-290) =
     CNN stack -> sigmoid on the 128 channel features, class-softmax attention pooling with dense_softmax; its GRU
@@ -421,3 +444,4 @@ if __name__ == "__main__":
     transforms_case()
     fpn_init_case()
     cnn_pred_case()
+    frame_d_case()

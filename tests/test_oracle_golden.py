@@ -328,3 +328,21 @@ def test_oracle_fpn_weights_init_statistics(golden_dir):
             continue
         assert abs(float(v.mean()) - mean) < 1e-5 + 1e-4 * abs(mean), k
         assert abs(float(v.abs().sum()) - asum) < 1e-3 + 1e-4 * asum, k
+
+
+def test_oracle_frame_discriminator_matches_reference_golden(golden_dir):
+    g = _load(golden_dir, "frame_d.npz")
+    N, T, seed = (int(v) for v in g["meta"])
+    x = torch.from_numpy(np.random.default_rng(seed).standard_normal((N, T, 256)).astype(np.float32)).requires_grad_()
+    m = co.Frame_Discriminator(input_dim=256, dropout=0)
+    assert list(m.state_dict().keys()) == [str(n) for n in g["state_names"]]
+    vals = seeded.load_seeded(m, seed + 1)
+    assert seeded.checksum(vals) == float(g["weight_checksum"][0])
+    m.train()
+    d = m(x)
+    np.testing.assert_allclose(d.detach().numpy(), g["out"], atol=1e-6)
+    up = torch.cos(torch.arange(d.numel(), dtype=torch.float32)).view_as(d) * 0.3
+    (d * up).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy()[:, ::7, ::5], g["dx"], atol=1e-7, rtol=1e-4)
+    for k, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.numpy(), g["grad/" + k], atol=1e-6, rtol=1e-4)
