@@ -177,6 +177,9 @@ class CRNN(_FlatModule):
         # gradients are stretched by the recurrence they share the chip with, which would make per-kernel durations
         # (bench.py's roofline object, rocprof summaries) describe the overlap rather than the kernels.
         self.overlap_rnn = os.environ.get("BSED_RNN_OVERLAP", "0") == "1"
+        # first block without its conv output / gradient tensors in HBM (csrc/block0.hip); 0 = the four-kernel form
+        # (conv0_fwd, glu16_fwd, glu16_bwd, conv0_wgrad), kept as the cross-check of the tests
+        self.block0_fused = os.environ.get("BSED_BLOCK0_FUSED", "1") != "0"
         self._side_stream = None
         # "bf16x3" (default): the 3x3 conv forward / data-gradient contractions and the GRU projection GEMMs run on the
         # bf16 matrix cores with split-fp32 operands (csrc/igemm3.hip; measured 5.5e-6 on the logits of the reference
@@ -301,6 +304,8 @@ class CRNN(_FlatModule):
         ph, pw = pool
         cw, cb = self.P(names[0] + ".weight"), self.P(names[0] + ".bias")
         taps, wsrc, s_tap = self._conv_taps(cw, Ww)
+        if first and co == 16 and self.block0_fused and Ww > 1:
+            return self._block0_forward(a, B, Hh, Ww, pool, names, drop, rng_stream, nbt, train)
         if first:
             y, stats = ops.conv0_fwd(a, cw, cb, B, Hh, Ww, co, want_stats=train)
         else:
@@ -336,6 +341,25 @@ class CRNN(_FlatModule):
                                   pool=(ph, pw), drop_p=drop, rng_stream=rng_stream, seed=self.seed)
         blk = dict(inp=a, y=y, mean=mean, invstd=invstd, scale=scale, shift=shift, H=Hh, W=Ww, cin=cin, co=co,
                    pool=(ph, pw), names=names, drop=drop, rng=rng_stream, first=first)
+        return pooled, blk
+
+    def _block0_forward(self, a, B, Hh, Ww, pool, names, drop, rng_stream, nbt, train):
+        """the first block with its conv output recomputed where needed instead of stored (csrc/block0.hip): batch
+        statistics from x alone, then conv + BN + GLU + dropout + pool in one pass x -> pooled"""
+        cw, cb = self.P(names[0] + ".weight"), self.P(names[0] + ".bias")
+        bn, glu = self.P(names[1]), self.P(names[2])
+        xr64 = None
+        if train:
+            stats, xr64 = ops.block0_stats(a, cw, cb, B, Hh, Ww)
+            mean, invstd, scale, shift = ops.bn_finalize(stats, 16, float(B * Hh * Ww), BN_EPS, BN_MOMENTUM,
+                                                         bn.weight, bn.bias, bn.running_mean, bn.running_var, nbt)
+        else:
+            mean = invstd = None
+            scale, shift = ops.bn_eval(16, BN_EPS, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        pooled = ops.block0_fwd(a, cw, cb, scale, shift, glu.weight, glu.bias, B, Hh, Ww, pool, drop, rng_stream,
+                                self.seed)
+        blk = dict(inp=a, y=None, xr64=xr64, mean=mean, invstd=invstd, scale=scale, shift=shift, H=Hh, W=Ww, cin=1,
+                   co=16, pool=pool, names=names, drop=drop, rng=rng_stream, first=True)
         return pooled, blk
 
     @staticmethod
@@ -425,6 +449,18 @@ class CRNN(_FlatModule):
         conv_n, bn_n, glu_n = blk["names"]
         glu, bn = self.P(glu_n), self.P(bn_n)
         drop_b, rng = blk["drop"], blk["rng"]
+        if blk["first"] and y is None:
+            # fused first block: y recomputed from x, g consumed in registers (BatchNorm-backward sums, Gx = sum g x_tap);
+            # conv0's weight gradient is assembled from Gx and the input's tap correlations (csrc/block0.hip)
+            cw, cb = self.P(conv_n + ".weight"), self.P(conv_n + ".bias")
+            pdw, pdb, st2, pgx, G = ops.block0_bwd(blk["inp"], cw, cb, blk["scale"], blk["shift"], glu.weight,
+                                                   glu.bias, dpool.contiguous(), B, Hh, Ww, (ph, pw), drop_b, rng, seed)
+            ops.reduce_partials(pdw, G, 1, 16, 16, 16, 16, glu.weight.grad, 0, 16, 1)
+            ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
+            coef = ops.bn_bwd(st2, co, float(B * Hh * Ww), bn.weight, blk["mean"], blk["invstd"], bn.weight.grad,
+                              bn.bias.grad, None, blk["inp"], apply=False)
+            ops.block0_wgrad_finish(pgx, G, blk["xr64"], coef, blk["mean"], cw, cb, cw.grad)
+            return None
         if co == 16:
             # one streaming pass: y, d_pooled -> g + partials of dW_glu, db_glu and the BN-backward sums
             g, pdw, pdb, st2, G = ops.glu16_bwd(y, blk["scale"], blk["shift"], glu.weight, glu.bias,

@@ -398,6 +398,54 @@ def glu16_bwd(y, scale, shift, wg, bg, dpool, B, H, W, pool, drop_p, rng_stream,
     return g, part_dw, part_db, part_st, G
 
 
+def block0_stats(x, cw, cb, NB, H, W):
+    """train-mode statistics of the first block from x alone: returns (stats (G,2,16) for bn_finalize, xr64 (54,) fp64)"""
+    G = int(min(2048, max(1, (NB * H * W) // 256)))
+    dev = x.device
+    stats = torch.empty((G, 2, 16), device=dev, dtype=torch.float32)
+    xr_part = torch.empty((G, 54), device=dev, dtype=torch.float32)
+    xr64 = torch.empty(54, device=dev, dtype=torch.float64)
+    _note("b0_stats_kernel", f"{H}x{W}", 2.0 * NB * H * W * (9 * 16 + 16 + 54), 4.0 * NB * H * W)
+    L.call("bsed_block0_stats", L.ptr(x), _fp(_dp(cw)), _fp(_dp(cb)), L.ptr(stats), L.ptr(xr_part),
+           L.ptr(xr64, torch.float64), _i(G), _i(NB), _i(H), _i(W), _i(16), L.stream())
+    return stats, xr64
+
+
+def block0_fwd(x, cw, cb, scale, shift, wg, bg, B, H, W, pool, drop_p, rng_stream, seed):
+    ph, pw = pool
+    out = torch.empty((B, H // ph, W // pw, 16), device=x.device, dtype=torch.float32)
+    _note(f"b0_fwd_kernel<{ph}>", f"{H}x{W}", 2.0 * B * H * W * (9 * 16 + 256),
+          4.0 * B * H * W * (1.0 + 16.0 / (ph * pw)))
+    L.call("bsed_block0_fwd", L.ptr(x), _fp(_dp(cw)), _fp(_dp(cb)), L.ptr(scale), L.ptr(shift), _fp(_dp(wg)),
+           _fp(_dp(bg)), L.ptr(out), _i(B), _i(H), _i(W), _i(16), _i(ph), _i(pw), ctypes.c_float(drop_p),
+           ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream())
+    return out
+
+
+def block0_bwd(x, cw, cb, scale, shift, wg, bg, dpool, B, H, W, pool, drop_p, rng_stream, seed):
+    """returns (part_dw (G,16,16), part_db (G,2,16), part_st (G,2,16), part_gx (G,9,16), G)"""
+    ph, pw = pool
+    dev = x.device
+    G = int(min(2048, B * (H // ph)))
+    part_dw = torch.empty((G, 16, 16), device=dev, dtype=torch.float32)
+    part_db = torch.empty((G, 2, 16), device=dev, dtype=torch.float32)
+    part_st = torch.empty((G, 2, 16), device=dev, dtype=torch.float32)
+    part_gx = torch.empty((G, 9, 16), device=dev, dtype=torch.float32)
+    _note(f"b0_bwd_kernel<{ph}>", f"{H}x{W}", 2.0 * B * H * W * (2 * 9 * 16 + 3 * 256),
+          4.0 * B * H * W * (1.0 + 16.0 / (ph * pw)))
+    L.call("bsed_block0_bwd", L.ptr(x), _fp(_dp(cw)), _fp(_dp(cb)), L.ptr(scale), L.ptr(shift), _fp(_dp(wg)),
+           _fp(_dp(bg)), L.ptr(dpool), L.ptr(part_dw), L.ptr(part_db), L.ptr(part_st), L.ptr(part_gx), _i(G), _i(B),
+           _i(H), _i(W), _i(16), _i(ph), _i(pw), ctypes.c_float(drop_p), ctypes.c_uint32(rng_stream),
+           ctypes.c_uint64(seed), L.stream())
+    return part_dw, part_db, part_st, part_gx, G
+
+
+def block0_wgrad_finish(part_gx, G, xr64, coef, mean, cw, cb, dst, accumulate=True):
+    _note("b0_wgrad_finish_kernel", f"G{G}", float(part_gx.numel()), 4.0 * part_gx.numel())
+    L.call("bsed_block0_wgrad_finish", L.ptr(part_gx), _i(G), L.ptr(xr64, torch.float64), L.ptr(coef), L.ptr(mean),
+           _fp(_dp(cw)), _fp(_dp(cb)), _fp(_dp(dst)), _i(1 if accumulate else 0), _i(16), L.stream())
+
+
 def glu_bwd_fused(y, scale, shift, wfwd, w, bias, dpool, B, H, W, C, pool, drop_p, rng_stream, seed):
     """returns (g, part_dw (G*slabs,C,C), part_db (G,2,C), part_st (G,2,C), G, slabs)"""
     ph, pw = pool
@@ -514,14 +562,15 @@ def bn_eval(C, eps, gamma, beta, rmean, rvar):
 def bn_bwd(stats, C, count, gamma, mean, invstd, dgamma, dbeta, g_inout, y, apply=True):
     """apply=False: only dgamma/dbeta and the (3,C) coefficients [A|B|C] of d_y = A g + B (y-mean) + C (returned);
     the consumer applies the map on load (conv0_wgrad)."""
-    dev = y.device
+    dev = stats.device
     coef = torch.empty((3, C), device=dev, dtype=torch.float32)
     _note("bn_bwd_apply_kernel" if apply else "stats_chunk_kernel+stats_finish_kernel", f"C{C}", 3.0 * y.numel() if apply else 0.0,
           12.0 * y.numel() if apply else 4.0 * stats.numel())
     L.call("bsed_bn_bwd", L.ptr(stats), ctypes.c_long(stats.shape[0]), _i(C), ctypes.c_double(count), _fp(_dp(gamma)),
            L.ptr(mean), L.ptr(invstd), _fp(_dp(dgamma)), _fp(_dp(dbeta)), _i(1),
            L.ptr(g_inout) if apply else None, L.ptr(y) if apply else None,
-           ctypes.c_long(y.numel()), L.ptr(coef), L.ptr(stats_scratch(C, dev), torch.float64), L.stream())
+           ctypes.c_long(y.numel() if apply else C), L.ptr(coef), L.ptr(stats_scratch(C, dev), torch.float64),
+           L.stream())
     return coef
 
 

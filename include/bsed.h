@@ -227,6 +227,28 @@ int bsed_glu16_bwd(const float* y, const float* scale, const float* shift, const
                    int H, int W, int C, int ph, int pw, float drop_p, uint32_t rng_stream, uint64_t seed,
                    void* stream);
 
+/* The whole first CNN block (conv3x3 1->16, BatchNorm, GLU, dropout, avg-pool: src/models/CNN.py:46-67, i = 0) WITHOUT
+ * its conv output and gradient tensors in HBM (csrc/block0.hip): y0 is a 9-tap stencil of the input and is recomputed
+ * where it is needed; BatchNorm's batch statistics come from x alone; conv0's weight gradient is assembled from
+ * Gx = sum g x_tap (taken by the backward kernel) and the input's tap correlations R / Sx (taken with the statistics).
+ *   stats : x (NB,H,W) -> stats (G,2,16) per-workgroup (sum y, sum y^2) for bsed_bn_finalize; xr_part (G,54) scratch;
+ *           xr64 (54) fp64 totals [Sx (9) | R upper triangle (45)] for bsed_block0_wgrad_finish
+ *   fwd   : x -> pooled (B,H/ph,W/pw,16), same values (bit for bit) as bsed_conv0_fwd + bsed_glu16_fwd
+ *   bwd   : x, dpool -> per-workgroup partials part_dw (G,16,16), part_db (G,2,16) [slot 0], part_st (G,2,16) =
+ *           (sum g, sum g*y) for bsed_bn_bwd (coefficients only), part_gx (G,9,16)
+ *   wgrad_finish : dst (16,1,3,3) (+)= A Gx + B (Yx - mean Sx) + C Sx with coef = [A|B|C] of bsed_bn_bwd */
+int bsed_block0_stats(const float* x, const float* cw, const float* cb, float* stats, float* xr_part, double* xr64,
+                      int G, int NB, int H, int W, int CO, void* stream);
+int bsed_block0_fwd(const float* x, const float* cw, const float* cb, const float* scale, const float* shift,
+                    const float* wg, const float* bg, float* out, int B, int H, int W, int CO, int ph, int pw,
+                    float drop_p, uint32_t rng_stream, uint64_t seed, void* stream);
+int bsed_block0_bwd(const float* x, const float* cw, const float* cb, const float* scale, const float* shift,
+                    const float* wg, const float* bg, const float* dpool, float* part_dw, float* part_db,
+                    float* part_st, float* part_gx, int G, int B, int H, int W, int CO, int ph, int pw, float drop_p,
+                    uint32_t rng_stream, uint64_t seed, void* stream);
+int bsed_block0_wgrad_finish(const float* part_gx, int G, const double* xr64, const float* coef, const float* mean,
+                             const float* cw, const float* cb, float* dst, int accumulate, int CO, void* stream);
+
 /* Fused GLU backward for C in {32,64,128} (csrc/glu_bwd.hip): y, d_pooled -> g = dL/d(BN output) in one pass, with
  * the three contractions (lin recompute, g, dW) chained on chip.  wfwd = bsed_pack_weight'ed W^T ([c][n]),
  * wbwd = the (C,C) Linear weight itself.  Outputs per-workgroup partials: part_dw (G*bsed_glu_bwd_slabs(C), C, C),
