@@ -126,7 +126,7 @@ def cpu_baseline(sr, seconds, threads):
 
 
 SPLIT_KERNEL = re.compile(r"3[a-z]?_kernel")      # *3_kernel / *3n / *3p / *3s: split-fp32 operands on the bf16 cores
-MFMA_KERNEL = re.compile(r"^(igemm|wgrad|glu_fwd3|glu_bwd3|glu_bwd_fused|gru_fwd_mfma|gru_bwd_mfma|glu16)")
+MFMA_KERNEL = re.compile(r"^(igemm|wgrad|glu_fwd3|glu_bwd3|glu_bwd_fused|gru_fwd_mfma|gru_bwd_mfma|glu16|b0_fwd|b0_bwd)")
 ALGORITHMIC_MB_PER_CLIP = {22050: 128.9, 32000: 186.9}     # SURVEY.md 8(d), fp32 activations, mel stage included
 STEP_GFLOP_PER_CLIP = {22050: 7.63, 32000: 11.05}           # SURVEY.md 8(d), train step = fwd + 2 x bwd
 
@@ -144,7 +144,7 @@ def kernel_roofline(name, launches, total_ms, flops_total, bytes_total):
     ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
     on_matrix = MFMA_KERNEL.search(name) is not None
     basis = ("dense bf16 MFMA 2500 / 3 (bf16x3 split-fp32 operands)" if split else
-             "fp32 MFMA 157.3 (v_mfma_f32_32x32x2_f32)" if on_matrix else "fp32 vector 157.3 (no matrix-core work in this kernel)")
+             "fp32 MFMA 157.3 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32, exact fp32)" if on_matrix else "fp32 vector 157.3 (no matrix-core work in this kernel)")
     r = {"traffic": None, "kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
          "algorithmic_gflop_per_launch": round(flops_total / launches / 1e9, 3),
          "algorithmic_mbytes_per_launch": round(bytes_total / launches / 1e6, 2),

@@ -207,6 +207,81 @@ __global__ __launch_bounds__(256) void b0_colsum64_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// Shared pieces of the forward / backward kernels.
+//
+// A wave owns 16 consecutive columns of PH stacked rows.  The (PH + 2) x 18 input window around them (zero outside the
+// map) lives in a WAVE-PRIVATE LDS tile: two global loads per lane and item (issued one item ahead), no workgroup
+// barrier -- LDS operations of one wave execute in order.  The convolution runs on the fp32 matrix cores like the GLU
+// contractions:  y^T[c][pos] = sum_t W[c][t] x_t[pos]  as three v_mfma_f32_16x16x4_f32 (taps 0-3, 4-7, 8 + padding)
+// with A[i = c][k] = W[c = p][4r + q] (lane constants), B[k][j = pos] = x_{4r+q}[pos p] (ONE LDS read per lane and
+// MFMA: the lane's tap offset is a lane constant) and the bias as initial accumulator; the D fragment is the lane's own
+// position and four channels.  Same accumulation chain in every kernel of this file.
+// ---------------------------------------------------------------------------------------------
+#define B0_WIN 18   // window columns: 16 + halo
+
+template <int PH>
+struct B0Win {
+  static constexpr int NE = (PH + 2) * B0_WIN;   // 72 (PH = 2) or 54 floats
+  static constexpr int NL = (NE + 63) / 64;      // loads per lane and item
+  int ej[NL], ec[NL];                            // (row, column) of the lane's window elements
+  bool ev[NL];
+  float v[NL];                                   // prefetched values
+  __device__ __forceinline__ void init(int lane) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int e = lane + 64 * k;
+      ev[k] = e < NE;
+      ej[k] = (e < NE ? e : 0) / B0_WIN;
+      ec[k] = (e < NE ? e : 0) % B0_WIN;
+    }
+  }
+  // issue the loads of the window whose first row / column are (r0 - 1, c0 - 1) in image b
+  __device__ __forceinline__ void fetch(const float* __restrict__ x, int b, int r0, int c0, int H, int W) {
+    const int base = b * H;   // NB * H * W < 2^31 (checked on the host): 32-bit element offsets
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int r = r0 - 1 + ej[k], c = c0 - 1 + ec[k];
+      const bool ok = r >= 0 && r < H && c >= 0 && c < W;
+      const float t = x[(base + min(max(r, 0), H - 1)) * W + min(max(c, 0), W - 1)];
+      v[k] = ok ? t : 0.f;
+    }
+  }
+  __device__ __forceinline__ void store(float* win, int lane) const {
+#pragma unroll
+    for (int k = 0; k < NL; ++k)
+      if (ev[k]) win[lane + 64 * k] = v[k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own reads below see the whole tile
+  }
+};
+
+// conv weights as MFMA A operands: aw[r] = W[c = p][t = 4r + q] (0 for t >= 9); window offsets of the lane's taps
+struct B0Conv {
+  float aw[3];
+  int off[3];      // (kh * 18 + kw) of tap min(4r + q, 8), plus the lane's column p
+  float bias[4];
+  __device__ __forceinline__ void init(const float* __restrict__ cw, const float* __restrict__ cb, int p, int q) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int t = 4 * r + q, tc = t < 9 ? t : 8;
+      aw[r] = t < 9 ? cw[p * 9 + t] : 0.f;
+      off[r] = (tc / 3) * B0_WIN + (tc % 3) + p;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias[i] = cb[4 * q + i];
+  }
+  // y of the lane's position in window row dh (its four channels 4q .. 4q+3)
+  __device__ __forceinline__ f32x4 run(const float* win, int dh) const {
+    float b0 = win[dh * B0_WIN + off[0]], b1 = win[dh * B0_WIN + off[1]], b2 = win[dh * B0_WIN + off[2]];
+    f32x4 c = {bias[0], bias[1], bias[2], bias[3]};
+    asm volatile("s_nop 4" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(c));
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[0], b0, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[1], b1, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[2], b2, c, 0, 0, 0);
+    return c;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
 // forward: x -> conv -> BN-apply -> Linear -> gate -> dropout -> PH x pw average pool -> pooled
 // ---------------------------------------------------------------------------------------------
 #define B0F_THREADS 512
@@ -217,33 +292,35 @@ __global__ __launch_bounds__(B0F_THREADS) void b0_fwd_kernel(
     const float* __restrict__ bg, float* __restrict__ out, int B, int H, int W, int pw, float drop_p,
     uint32_t rng_stream, uint64_t seed) {
   constexpr int C = B0_C;
+  __shared__ float wins[B0F_THREADS / 64][(PH + 2) * B0_WIN + 8];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
   const int col = wave * 16 + p;
   const int Hp = H / PH, Wp = W / pw;
-  B0W K;
-  b0_load_w(cw, cb, q, K);
+  float* win = wins[wave];
+  B0Conv K;
+  K.init(cw, cb, p, q);
   float a1[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) a1[kk] = wg[p * C + 4 * q + kk];
   float sc[4], sh[4], bi[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { sc[i] = scale[4 * q + i]; sh[i] = shift[4 * q + i]; bi[i] = bg[4 * q + i]; }
-  const uint32_t dkey = drop_key(rng_stream, seed), dthr = drop_threshold(drop_p);
+  const uint32_t dkey = drop_key(rng_stream, seed), dthr = drop_threshold16(drop_p);
   const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
   const float inv = 1.0f / (float)(PH * pw);
   const int chunks = (W + B0F_THREADS / 4 - 1) / (B0F_THREADS / 4);
   B0Idx cur, nxt;
   cur.init(blockIdx.x, gridDim.x, Hp, chunks);
-
-  B0X<PH> nx;
-  auto fetch = [&](const B0Idx& I) {
-    b0_fetch<PH>(x, I.b, I.hp * PH, min(I.ch * (B0F_THREADS / 4) + col, W - 1), H, W, nx);
-  };
-  fetch(cur);
+  B0Win<PH> X;
+  X.init(lane);
+  X.fetch(x, cur.b < B ? cur.b : 0, cur.hp * PH, cur.ch * (B0F_THREADS / 4) + wave * 16, H, W);
   for (; cur.b < B; cur = nxt) {
-    const B0X<PH> X = nx;
+    X.store(win, lane);
     nxt = cur.next();
-    fetch(nxt.b < B ? nxt : cur);   // the last prefetch re-reads the current item: no branch around the loads
+    {
+      const B0Idx& I = nxt.b < B ? nxt : cur;   // the last prefetch re-reads the current item: no branch
+      X.fetch(x, I.b, I.hp * PH, I.ch * (B0F_THREADS / 4) + wave * 16, H, W);
+    }
     const int hp = cur.hp, b = cur.b;
     const int w = cur.ch * (B0F_THREADS / 4) + col;
     const bool ok = w < W;
@@ -253,43 +330,42 @@ __global__ __launch_bounds__(B0F_THREADS) void b0_fwd_kernel(
     for (int dh = 0; dh < PH; ++dh) {
       const int h = hp * PH + dh;
       const size_t pos = ((size_t)b * H + h) * W + wc;
-      float x9[9];
-#pragma unroll
-      for (int t = 0; t < 9; ++t) x9[t] = X.v[dh + t / 3][t % 3];
+      const f32x4 y = K.run(win, dh);
       float xn[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xn[i] = fmaf(b0_conv1(x9, K.w[i], K.b[i]), sc[i], sh[i]);
+      for (int i = 0; i < 4; ++i) xn[i] = fmaf(y[i], sc[i], sh[i]);
       const f32x4 lin = b0_mm16(a1, xn[0], xn[1], xn[2], xn[3], f32x4{0.f, 0.f, 0.f, 0.f});
+      float dm[4];
+      drop_mul2((uint64_t)pos * C + 4 * q, dkey, dthr, dscale, dm[0], dm[1]);
+      drop_mul2((uint64_t)pos * C + 4 * q + 2, dkey, dthr, dscale, dm[2], dm[3]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        pooled[i] += (lin[i] + bi[i]) * sigmoid_fast(xn[i]) *
-                     drop_mul((uint64_t)pos * C + 4 * q + i, dkey, dthr, dscale);
+      for (int i = 0; i < 4; ++i) pooled[i] += (lin[i] + bi[i]) * sigmoid_fast(xn[i]) * dm[i];
     }
     if (pw == 2) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) pooled[i] += __shfl_xor(pooled[i], 1, 64);   // the neighbouring column
     }
-    if (ok && (w & (pw - 1)) == 0 && (w / pw) < Wp) {
+    if (ok && (w & (pw - 1)) == 0 && (w >> (pw >> 1)) < Wp) {   // pw is 1 or 2
       const float4 o = make_float4(pooled[0] * inv, pooled[1] * inv, pooled[2] * inv, pooled[3] * inv);
-      *reinterpret_cast<float4*>(out + (((size_t)b * Hp + hp) * Wp + w / pw) * C + 4 * q) = o;
+      *reinterpret_cast<float4*>(out + (((size_t)b * Hp + hp) * Wp + (w >> (pw >> 1))) * C + 4 * q) = o;
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // backward: x, d_pooled -> partials of dW_glu (G,16,16), db_glu (G,2,16), (sum g, sum g y) (G,2,16), Gx (G,9,16)
+//
+// dW_glu[n][c] = sum_pos d_lin[pos][n] xn[pos][c] contracts over POSITIONS, which the lane map keeps in the lane index:
+// both operands go through a wave-private LDS tile ([16 positions][16 channels], pitch 20: the float4 row stores and
+// the transposed dword reads are both conflict-free) and come back with positions in the MFMA's k index (lane quarter
+// q <-> position 4q + s for MFMA s), channel in p: four more v_mfma_f32_16x16x4_f32 per 16 positions, ONE four-register
+// accumulator per lane instead of 64 VALU accumulators and 12 cross-lane shuffles per position.
 // ---------------------------------------------------------------------------------------------
 #define B0B_THREADS 256
-struct f4b { float v[4]; };
-__device__ __forceinline__ f4b b0_shfl_xor4(const f4b& a, int s) {
-  f4b r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r.v[i] = __shfl_xor(a.v[i], s, 64);
-  return r;
-}
+#define B0_TP 20   // pitch of the transpose tiles (floats)
 
 template <int PH>
-__global__ __launch_bounds__(B0B_THREADS, 2) void b0_bwd_kernel(
+__global__ __launch_bounds__(B0B_THREADS, 3) void b0_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ cw, const float* __restrict__ cb,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ wg,
     const float* __restrict__ bg, const float* __restrict__ dpool, float* __restrict__ part_dw,
@@ -297,31 +373,33 @@ __global__ __launch_bounds__(B0B_THREADS, 2) void b0_bwd_kernel(
     float drop_p, uint32_t rng_stream, uint64_t seed) {
   constexpr int C = B0_C;
   __shared__ float red[B0B_THREADS * 17];
+  __shared__ float wins[B0B_THREADS / 64][(PH + 2) * B0_WIN + 8];
+  __shared__ __align__(16) float tiles[B0B_THREADS / 64][2][16 * B0_TP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
   const int col = wave * 16 + p;
   const int Hp = H / PH, Wp = W / pw;
   const int spw = pw >> 1;
-  B0W K;
-  b0_load_w(cw, cb, q, K);
+  float* win = wins[wave];
+  float* tdl = tiles[wave][0];
+  float* txn = tiles[wave][1];
+  B0Conv K;
+  K.init(cw, cb, p, q);
+  int xoff[9];   // the nine taps at the lane's own position (VALU Gx)
+#pragma unroll
+  for (int t = 0; t < 9; ++t) xoff[t] = (t / 3) * B0_WIN + (t % 3) + p;
   float a1[4], a2[4];   // W[n = p][4q + kk]  and  W[4q + kk][c = p]
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) { a1[kk] = wg[p * C + 4 * q + kk]; a2[kk] = wg[(4 * q + kk) * C + p]; }
   float sc[4], sh[4], bi[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { sc[i] = scale[4 * q + i]; sh[i] = shift[4 * q + i]; bi[i] = bg[4 * q + i]; }
-  const uint32_t dkey = drop_key(rng_stream, seed), dthr = drop_threshold(drop_p);
+  const uint32_t dkey = drop_key(rng_stream, seed), dthr = drop_threshold16(drop_p);
   const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
   const float inv = 1.0f / (float)(PH * pw);
 
-  float dwa[4][4][4];   // dW[4q+i][4(q^s)+kk]
-  float gxa[4][9];      // Gx[4q+i][t]
+  f32x4 dwacc = {0.f, 0.f, 0.f, 0.f};   // dW[n = 4q + v][c = p]
+  float gxa[4][9];                      // Gx[4q+i][t]
   float dba[4] = {0.f, 0.f, 0.f, 0.f}, sga[4] = {0.f, 0.f, 0.f, 0.f}, sgya[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) dwa[s][i][kk] = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -331,17 +409,18 @@ __global__ __launch_bounds__(B0B_THREADS, 2) void b0_bwd_kernel(
   const int chunks = (W + B0B_THREADS / 4 - 1) / (B0B_THREADS / 4);
   B0Idx cur, nxt;
   cur.init(blockIdx.x, gridDim.x, Hp, chunks);
-  B0X<PH> nx;
+  B0Win<PH> X;
+  X.init(lane);
   float4 nd = make_float4(0.f, 0.f, 0.f, 0.f);
   auto fetch = [&](const B0Idx& I) {
+    X.fetch(x, I.b, I.hp * PH, I.ch * (B0B_THREADS / 4) + wave * 16, H, W);
     const int w = min(I.ch * (B0B_THREADS / 4) + col, W - 1);
-    b0_fetch<PH>(x, I.b, I.hp * PH, w, H, W, nx);
     const int wpi = min(w >> spw, Wp - 1);
     nd = *reinterpret_cast<const float4*>(dpool + (((size_t)I.b * Hp + I.hp) * Wp + wpi) * C + 4 * q);
   };
-  fetch(cur);
+  if (cur.b < B) fetch(cur);
   for (; cur.b < B; cur = nxt) {
-    const B0X<PH> X = nx;
+    X.store(win, lane);
     const float4 cd = nd;
     nxt = cur.next();
     fetch(nxt.b < B ? nxt : cur);
@@ -354,27 +433,33 @@ __global__ __launch_bounds__(B0B_THREADS, 2) void b0_bwd_kernel(
     for (int dh = 0; dh < PH; ++dh) {
       const int h = hp * PH + dh;
       const size_t pos = ((size_t)b * H + h) * W + min(w, W - 1);
-      float x9[9];
+      const f32x4 yv = K.run(win, dh);
+      float xn[4];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) x9[t] = X.v[dh + t / 3][t % 3];
-      float yv[4];
-      f4b xs[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        yv[i] = b0_conv1(x9, K.w[i], K.b[i]);
-        xs[0].v[i] = fmaf(yv[i], sc[i], sh[i]);
-      }
-      const f32x4 lin = b0_mm16(a1, xs[0].v[0], xs[0].v[1], xs[0].v[2], xs[0].v[3], f32x4{0.f, 0.f, 0.f, 0.f});
-      float dl[4];
+      for (int i = 0; i < 4; ++i) xn[i] = fmaf(yv[i], sc[i], sh[i]);
+      const f32x4 lin = b0_mm16(a1, xn[0], xn[1], xn[2], xn[3], f32x4{0.f, 0.f, 0.f, 0.f});
+      float dl[4], dm[4];
       f32x4 gt;
+      drop_mul2((uint64_t)pos * C + 4 * q, dkey, dthr, dscale, dm[0], dm[1]);
+      drop_mul2((uint64_t)pos * C + 4 * q + 2, dkey, dthr, dscale, dm[2], dm[3]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float sg = sigmoid_fast(xs[0].v[i]);
-        const float dr = dres[i] * drop_mul((uint64_t)pos * C + 4 * q + i, dkey, dthr, dscale);
+        const float sg = sigmoid_fast(xn[i]);
+        const float dr = dres[i] * dm[i];
         dl[i] = dr * sg;
         gt[i] = dr * (lin[i] + bi[i]) * sg * (1.0f - sg);
       }
+      // operands of the dW contraction into the transpose tiles (row = position p, columns 4q .. 4q+3)
+      *reinterpret_cast<float4*>(tdl + p * B0_TP + 4 * q) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+      *reinterpret_cast<float4*>(txn + p * B0_TP + 4 * q) = make_float4(xn[0], xn[1], xn[2], xn[3]);
       const f32x4 g = b0_mm16(a2, dl[0], dl[1], dl[2], dl[3], gt);   // g = d_lin W + gate term (0 on idle columns)
+      float x9[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) x9[t] = win[dh * B0_WIN + xoff[t]];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tiles written (all lanes of the wave), taps read
+      float ta[4], tb[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { ta[s] = tdl[(4 * q + s) * B0_TP + p]; tb[s] = txn[(4 * q + s) * B0_TP + p]; }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         dba[i] += dl[i];
@@ -383,29 +468,35 @@ __global__ __launch_bounds__(B0B_THREADS, 2) void b0_bwd_kernel(
 #pragma unroll
         for (int t = 0; t < 9; ++t) gxa[i][t] = fmaf(g[i], x9[t], gxa[i][t]);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 4" : "+v"(ta[0]), "+v"(ta[1]), "+v"(ta[2]), "+v"(ta[3]), "+v"(tb[0]),
+                   "+v"(tb[1]), "+v"(tb[2]), "+v"(tb[3]), "+v"(dwacc) : : "memory");
 #pragma unroll
-      for (int s = 1; s < 4; ++s) xs[s] = b0_shfl_xor4(xs[0], 16 * s);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) dwa[s][i][kk] = fmaf(dl[i], xs[s].v[kk], dwa[s][i][kk]);
+      for (int s = 0; s < 4; ++s) dwacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s], tb[s], dwacc, 0, 0, 0);
     }
   }
 
-  // workgroup reduction over the 64 threads that share a quarter index q, 16 values per pass:
-  //   passes 0-3 dW (partner quarter q ^ pass), 4 db / sum g / sum g y, 5-7 Gx (12 values each)
+  // workgroup reduction.  pass 0: the waves' dW accumulators (already summed over positions); passes 1-4: values kept
+  // per lane, summed over the 64 threads that share a quarter index q, 16 values per pass (db / sum g / sum g y, Gx)
+  const size_t gblk = blockIdx.x;
+  __syncthreads();
 #pragma unroll
-  for (int pass = 0; pass < 8; ++pass) {
+  for (int v = 0; v < 4; ++v) red[(wave * 4 + v) * 64 + lane] = dwacc[v];
+  __syncthreads();
+  {
+    const int v = tid >> 6, l = tid & 63;   // element (n = 4 * (l >> 4) + v, c = l & 15)
+    float s = 0.f;
+    for (int wv = 0; wv < B0B_THREADS / 64; ++wv) s += red[(wv * 4 + v) * 64 + l];
+    part_dw[(gblk * C + 4 * (l >> 4) + v) * C + (l & 15)] = s;
+  }
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       float v;
-      if (pass < 4) v = dwa[pass][j >> 2][j & 3];
-      else if (pass == 4) v = j < 4 ? dba[j & 3] : (j < 8 ? sga[j & 3] : (j < 12 ? sgya[j & 3] : 0.f));
+      if (pass == 0) v = j < 4 ? dba[j & 3] : (j < 8 ? sga[j & 3] : (j < 12 ? sgya[j & 3] : 0.f));
       else {
-        const int e = (pass - 5) * 12 + j;   // e = i * 9 + t, 36 values over three passes of 12
+        const int e = (pass - 1) * 12 + j;   // e = i * 9 + t, 36 values over three passes of 12
         v = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -421,10 +512,7 @@ __global__ __launch_bounds__(B0B_THREADS, 2) void b0_bwd_kernel(
       float s = 0.f;
       for (int wv = 0; wv < B0B_THREADS / 64; ++wv)
         for (int pp = 0; pp < 16; ++pp) s += red[(wv * 64 + 16 * rq + pp) * 17 + j];
-      const size_t gblk = blockIdx.x;
-      if (pass < 4) {
-        part_dw[(gblk * C + 4 * rq + (j >> 2)) * C + 4 * (rq ^ pass) + (j & 3)] = s;
-      } else if (pass == 4) {
+      if (pass == 0) {
         if (j < 4) {
           part_db[(gblk * 2 + 0) * C + 4 * rq + j] = s;
           part_db[(gblk * 2 + 1) * C + 4 * rq + j] = 0.f;
@@ -434,7 +522,7 @@ __global__ __launch_bounds__(B0B_THREADS, 2) void b0_bwd_kernel(
           part_st[(gblk * 2 + 1) * C + 4 * rq + (j - 8)] = s;
         }
       } else if (j < 12) {
-        const int e = (pass - 5) * 12 + j, i = e / 9, t = e % 9;
+        const int e = (pass - 1) * 12 + j, i = e / 9, t = e % 9;
         part_gx[(gblk * 9 + t) * C + 4 * rq + i] = s;
       }
     }
@@ -496,8 +584,8 @@ extern "C" int bsed_block0_fwd(const float* x, const float* cw, const float* cb,
                                float drop_p, uint32_t rng_stream, uint64_t seed, void* stream) {
   BSED_CHECK_ARG(x && cw && cb && scale && shift && wg && bg && out, "bsed_block0_fwd: null tensor");
   BSED_CHECK_ARG(CO == B0_C, "bsed_block0_fwd: built for 16 first-layer channels (got %d)", CO);
-  BSED_CHECK_ARG(B > 0 && H > 0 && W > 0 && (ph == 1 || ph == 2) && (pw == 1 || pw == 2) && W % pw == 0 && H >= ph,
-                 "bsed_block0_fwd: bad shape");
+  BSED_CHECK_ARG(B > 0 && H > 0 && W > 0 && (ph == 1 || ph == 2) && (pw == 1 || pw == 2) && W % pw == 0 && H >= ph &&
+                     (long)B * H * W < (1L << 31), "bsed_block0_fwd: bad shape");
   const long items = (long)B * (H / ph) * ((W + B0F_THREADS / 4 - 1) / (B0F_THREADS / 4));
   const dim3 grid((unsigned)std::min<long>(items, 8192));
   hipStream_t s = (hipStream_t)stream;
@@ -520,7 +608,7 @@ extern "C" int bsed_block0_bwd(const float* x, const float* cw, const float* cb,
   BSED_CHECK_ARG(CO == B0_C, "bsed_block0_bwd: built for 16 first-layer channels (got %d)", CO);
   BSED_CHECK_ARG(B > 0 && H > 0 && W > 0 && G > 0 && (ph == 1 || ph == 2) && (pw == 1 || pw == 2) && W % pw == 0 &&
                      H >= ph, "bsed_block0_bwd: bad shape");
-  BSED_CHECK_ARG((long)B * (H / ph) * ((W + 63) / 64) + G < (1L << 31), "bsed_block0_bwd: too many rows");
+  BSED_CHECK_ARG((long)B * H * W < (1L << 31), "bsed_block0_bwd: too many positions");
   hipStream_t s = (hipStream_t)stream;
   if (ph == 2)
     hipLaunchKernelGGL(b0_bwd_kernel<2>, dim3(G), dim3(B0B_THREADS), 0, s, x, cw, cb, scale, shift, wg, bg, dpool,

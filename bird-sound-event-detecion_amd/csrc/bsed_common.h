@@ -126,6 +126,18 @@ __device__ __forceinline__ float drop_mul(uint64_t e, uint32_t key, uint32_t thr
   return (h >> 8) >= thr ? scale : 0.f;
 }
 
+// Two keep-multipliers from ONE hash (the first CNN block, whose per-element work is what bounds its kernels): the
+// elements e (even) and e + 1 take the low / high 16 bits of the hash of e >> 1 against a 16-bit threshold.  The keep
+// probability is 1 - floor(65536 p) / 65536: within 1.6e-5 of 1 - p for any p, exact for p = 0.5.
+__device__ __forceinline__ uint32_t drop_threshold16(float p) { return (uint32_t)(p * 65536.0f); }
+__device__ __forceinline__ void drop_mul2(uint64_t e_even, uint32_t key, uint32_t thr16, float scale, float& m0,
+                                          float& m1) {
+  const uint64_t e = e_even >> 1;
+  const uint32_t h = mix32((uint32_t)e * 0x9E3779B1u + key + (uint32_t)(e >> 32) * 0x85ebca6bu);
+  m0 = (h & 0xFFFFu) >= thr16 ? scale : 0.f;
+  m1 = (h >> 16) >= thr16 ? scale : 0.f;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

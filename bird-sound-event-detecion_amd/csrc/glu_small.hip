@@ -60,7 +60,7 @@ __global__ __launch_bounds__(GS_THREADS) void glu16_fwd_kernel(
   float sc[4], sh[4], bi[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { sc[i] = scale[4 * q + i]; sh[i] = shift[4 * q + i]; bi[i] = bg[4 * q + i]; }
-  const uint32_t dkey = drop_key(rng_stream, seed), dthr = drop_threshold(drop_p);
+  const uint32_t dkey = drop_key(rng_stream, seed), dthr = drop_threshold16(drop_p);
   const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
   const float inv = 1.0f / (float)(ph * pw);
 
@@ -79,10 +79,11 @@ __global__ __launch_bounds__(GS_THREADS) void glu16_fwd_kernel(
         const float xn2 = fmaf(v.z, sc[2], sh[2]), xn3 = fmaf(v.w, sc[3], sh[3]);
         const f32x4 lin = mm16(a1, xn0, xn1, xn2, xn3, f32x4{0.f, 0.f, 0.f, 0.f});
         const float xn[4] = {xn0, xn1, xn2, xn3};
+        float dm[4];
+        drop_mul2((uint64_t)pos * C + 4 * q, dkey, dthr, dscale, dm[0], dm[1]);
+        drop_mul2((uint64_t)pos * C + 4 * q + 2, dkey, dthr, dscale, dm[2], dm[3]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          pooled[i] += (lin[i] + bi[i]) * sigmoid_fast(xn[i]) *
-                       drop_mul((uint64_t)pos * C + 4 * q + i, dkey, dthr, dscale);
+        for (int i = 0; i < 4; ++i) pooled[i] += (lin[i] + bi[i]) * sigmoid_fast(xn[i]) * dm[i];
       }
       if (pw == 2) {
 #pragma unroll
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(GB16_THREADS, 3) void glu16_bwd_kernel(
   float sc[4], sh[4], bi[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { sc[i] = scale[4 * q + i]; sh[i] = shift[4 * q + i]; bi[i] = bg[4 * q + i]; }
-  const uint32_t dkey = drop_key(rng_stream, seed), dthr = drop_threshold(drop_p);
+  const uint32_t dkey = drop_key(rng_stream, seed), dthr = drop_threshold16(drop_p);
   const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
   const float inv = 1.0f / (float)(ph * pw);
 
@@ -166,12 +167,14 @@ __global__ __launch_bounds__(GB16_THREADS, 3) void glu16_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) xs[0].v[i] = fmaf(yv[i], sc[i], sh[i]);
     const f32x4 lin = mm16(a1, xs[0].v[0], xs[0].v[1], xs[0].v[2], xs[0].v[3], f32x4{0.f, 0.f, 0.f, 0.f});
-    float dl[4];
+    float dl[4], dm[4];
     f32x4 gt;
+    drop_mul2((uint64_t)pos * C + 4 * q, dkey, dthr, dscale, dm[0], dm[1]);
+    drop_mul2((uint64_t)pos * C + 4 * q + 2, dkey, dthr, dscale, dm[2], dm[3]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float sg = sigmoid_fast(xs[0].v[i]);
-      const float dr = dres[i] * pmask * drop_mul((uint64_t)pos * C + 4 * q + i, dkey, dthr, dscale);
+      const float dr = dres[i] * pmask * dm[i];
       dl[i] = dr * sg;
       gt[i] = dr * (lin[i] + bi[i]) * sg * (1.0f - sg);
     }
