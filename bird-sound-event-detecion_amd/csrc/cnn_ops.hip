@@ -250,11 +250,25 @@ __global__ __launch_bounds__(256) void stats_chunk_kernel(const float* __restric
   const long per = (ntiles + nchunks - 1) / nchunks;
   const long t0 = chunk * per, t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
   double s0 = 0.0, s1 = 0.0;
-  if (c < C)
-    for (long t = t0 + g; t < t1; t += 8) {
+  if (c < C) {
+    // four tiles per trip, all eight loads issued before the first add: the loop is a chain of L2 latencies otherwise
+    // (fixed summation order: ((t, t+8), (t+16, t+24)) per trip, trips in order)
+    long t = t0 + g;
+    for (; t + 24 < t1; t += 32) {
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = partial[((t + 8 * u) * 2 + 0) * C + c];
+        b[u] = partial[((t + 8 * u) * 2 + 1) * C + c];
+      }
+      s0 += ((double)a[0] + (double)a[1]) + ((double)a[2] + (double)a[3]);
+      s1 += ((double)b[0] + (double)b[1]) + ((double)b[2] + (double)b[3]);
+    }
+    for (; t < t1; t += 8) {
       s0 += (double)partial[(t * 2 + 0) * C + c];
       s1 += (double)partial[(t * 2 + 1) * C + c];
     }
+  }
   sm[0][tid] = s0; sm[1][tid] = s1;
   __syncthreads();
   if (g == 0 && c < C) {
@@ -272,11 +286,23 @@ __global__ __launch_bounds__(256) void stats_finish_kernel(const double* __restr
   const int cl = tid & 31, g = tid >> 5;
   const int c = blockIdx.x * 32 + cl;
   double s0 = 0.0, s1 = 0.0;
-  if (c < C)
-    for (int k = g; k < nchunks; k += 8) {
+  if (c < C) {
+    int k = g;
+    for (; k + 24 < nchunks; k += 32) {   // four chunks per trip, loads first (see stats_chunk_kernel)
+      double a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = chunks[((size_t)(k + 8 * u) * 2 + 0) * C + c];
+        b[u] = chunks[((size_t)(k + 8 * u) * 2 + 1) * C + c];
+      }
+      s0 += (a[0] + a[1]) + (a[2] + a[3]);
+      s1 += (b[0] + b[1]) + (b[2] + b[3]);
+    }
+    for (; k < nchunks; k += 8) {
       s0 += chunks[((size_t)k * 2 + 0) * C + c];
       s1 += chunks[((size_t)k * 2 + 1) * C + c];
     }
+  }
   sm[0][tid] = s0; sm[1][tid] = s1;
   __syncthreads();
   if (g == 0 && c < C) {
@@ -296,8 +322,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
   for (int cb = 0; cb < C; cb += 32) {
     const int c = cb + cl;
     float s = 0.f;
-    if (c < C)
-      for (long r = r0 + g; r < r1; r += 8) s += in[r * pitch + c];
+    if (c < C) {
+      long r = r0 + g;
+      for (; r + 24 < r1; r += 32) {   // four rows per trip, loads first
+        const float a0 = in[r * pitch + c], a1 = in[(r + 8) * pitch + c], a2 = in[(r + 16) * pitch + c],
+                    a3 = in[(r + 24) * pitch + c];
+        s += (a0 + a1) + (a2 + a3);
+      }
+      for (; r < r1; r += 8) s += in[r * pitch + c];
+    }
     __syncthreads();
     sm[tid] = s;
     __syncthreads();

@@ -682,6 +682,164 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
 }
 
 // ---------------------------------------------------------------------------------------------
+// 1-tap weight gradient (GLU linears, GRU input / recurrent weights) as a STREAMING kernel.
+//
+// dW (CIN x N) = sum over positions of in^T dy reads each activation byte once and does 2 N (or 2 CIN) FLOP per byte:
+// a read-only, HBM-bound pass (a tuned read-only stream gets 6.3 TB/s on this part, tools/probe/hbm_read_probe.hip).
+// wgrad3_kernel runs these shapes with ONE 128-position tile in 128 KB of LDS: a single workgroup per CU whose loads,
+// operand split and MFMAs follow each other -- nothing is in flight while it computes (3.0-3.2 TB/s on the large shapes,
+// 1.1-1.7 on the GRU ones).  Here a workgroup (8 waves, one per CU) owns a 128 x 128 slab of dW and streams 64-position
+// tiles through TWO LDS stages (bf16 hi / lo planes, 64 KB each) with the global loads running TWO tiles ahead in
+// registers: while tile t is in the matrix cores, tile t+1 waits in registers or is being split into the other stage
+// and tile t+2 is in flight -- 64-128 KB of loads outstanding per CU at any time, one barrier per tile.
+// Operand images, swizzle and the transposing fragment reads are those of wgrad3_kernel (results are bit-identical:
+// same products, same accumulation order per slab; only the tile boundaries of the partial slabs differ).
+// ---------------------------------------------------------------------------------------------
+#define W1_TP 64
+#define W1_THREADS 512
+#define W1_PLANE (W1_TP * 128 * 2)   // bytes of one bf16 plane of a stage
+#define W1_STAGE (4 * W1_PLANE)      // Xh | Xl | DYh | DYl
+
+struct W1Set { float4 x[4], d[4]; };
+
+template <bool SHIFT>
+__global__ __launch_bounds__(W1_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad1_kernel(const WgradParams P) {
+  const BsedWgradDesc& p = P.d;
+  extern __shared__ __align__(16) uint32_t smw[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int cz0 = blockIdx.z * 128, n0 = blockIdx.y * 128;
+  const long M = (long)p.NB * p.H * p.W;
+  const int ntile = (int)((M + W1_TP - 1) / W1_TP);
+  // this wave's two 32 x 32 blocks: input-channel chunk cit, dy tiles nt0 and nt0 + 2
+  const int cit = wave & 3, nt0 = wave >> 2;
+  const int gq = (lane >> 2) & 3, gc = 4 * (lane & 3), gh = (lane >> 4) & 1;
+  const uint32_t base = (uint32_t)(uintptr_t)smw;
+  uint32_t xa[2], xb[2][2];
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    const int mk = 8 * lh + 4 * rd + gq;
+    xa[rd] = base + 2 * (mk * 128 + (w3_chunk(cit, mk, 4) << 5) + 16 * gh + gc);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      xb[s][rd] = base + 2 * W1_PLANE + 2 * (mk * 128 + (w3_chunk(nt0 + 2 * s, mk, 4) << 5) + 16 * gh + gc);
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+
+  // loads: thread -> channel quad c4 (constant) of positions p0 + 16 u
+  const int c4 = tid & 31, p0 = tid >> 5;
+  const bool xok = cz0 + 4 * c4 < p.CIN, dok = n0 + 4 * c4 < p.N;
+  const float* xsrc = p.in + cz0 + 4 * (xok ? c4 : 0);
+  const float* dsrc = p.dy + n0 + 4 * (dok ? c4 : 0);
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.a_scale && xok) {
+    sc = *reinterpret_cast<const float4*>(p.a_scale + cz0 + 4 * c4);
+    sh = *reinterpret_cast<const float4*>(p.a_shift + cz0 + 4 * c4);
+  }
+  const int shift = SHIFT ? p.dh[0] * p.W + p.dw[0] : 0;
+  const int so = p0 * 128 + (w3_chunk(c4 >> 3, p0, 4) << 5) + 4 * (c4 & 7);   // ushorts; + 16 u * 128 per u
+  w3_lds_u16* lds = (w3_lds_u16*)smw;
+
+  uint32_t xmask = 0, dmask = 0;   // validity bits of the set being loaded are recomputed at convert time
+  auto issue = [&](int tile, W1Set& S) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long m = (long)tile * W1_TP + p0 + 16 * u;
+      const long mc = m < M ? m : M - 1;   // clamped: no branch around the loads, idle rows are zeroed at convert time
+      long ms = mc;
+      if (SHIFT) {
+        ms = mc + shift;
+        ms = ms < 0 ? 0 : (ms >= M ? M - 1 : ms);
+      }
+      S.x[u] = *reinterpret_cast<const float4*>(xsrc + (size_t)ms * p.in_pitch);
+      S.d[u] = *reinterpret_cast<const float4*>(dsrc + (size_t)mc * p.dy_pitch);
+    }
+  };
+  auto convert = [&](int tile, const W1Set& S, int stage) {
+    w3_lds_u16* xh = lds + stage * (W1_STAGE / 2);
+    w3_lds_u16* xl = xh + W1_PLANE / 2;
+    w3_lds_u16* dh_ = xh + W1_PLANE;
+    w3_lds_u16* dl = dh_ + W1_PLANE / 2;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long m = (long)tile * W1_TP + p0 + 16 * u;
+      bool okx = m < M && xok;
+      if (SHIFT) {
+        const int rem = (int)(m % ((long)p.H * p.W));
+        const int h = rem / p.W + p.dh[0], w = rem % p.W + p.dw[0];
+        okx = okx && h >= 0 && h < p.H && w >= 0 && w < p.W;
+      }
+      const bool okd = m < M && dok;
+      float4 v = S.x[u];
+      v.x = okx ? fmaf(v.x, sc.x, sh.x) : 0.f; v.y = okx ? fmaf(v.y, sc.y, sh.y) : 0.f;
+      v.z = okx ? fmaf(v.z, sc.z, sh.z) : 0.f; v.w = okx ? fmaf(v.w, sc.w, sh.w) : 0.f;
+      w3_store4(xh, xl, so + 16 * u * 128, v);
+      float4 g = S.d[u];
+      g.x = okd ? g.x : 0.f; g.y = okd ? g.y : 0.f; g.z = okd ? g.z : 0.f; g.w = okd ? g.w : 0.f;
+      w3_store4(dh_, dl, so + 16 * u * 128, g);
+    }
+  };
+  auto mma = [&](int stage) {
+    const uint32_t so_ = stage * W1_STAGE;
+#pragma unroll
+    for (int k = 0; k < W1_TP / 16; ++k) {
+      const uint32_t ko = so_ + k * 16 * 128 * 2;
+      const w3_bf16x8 ah = w3_frag(xa[0] + ko, xa[1] + ko);
+      const w3_bf16x8 al = w3_frag(xa[0] + ko + W1_PLANE, xa[1] + ko + W1_PLANE);
+      w3_bf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bh[s] = w3_frag(xb[s][0] + ko, xb[s][1] + ko);
+        bl[s] = w3_frag(xb[s][0] + ko + W1_PLANE, xb[s][1] + ko + W1_PLANE);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s], acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s], acc[s], 0, 0, 0);
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s], acc[s], 0, 0, 0);
+      }
+    }
+  };
+  (void)xmask; (void)dmask;
+
+  // tiles of this workgroup: t0, t0 + G, ...   (n of them; tile indices past the end load clamped rows that convert
+  // zeroes and nobody multiplies)
+  const int t0 = blockIdx.x, G = gridDim.x;
+  const int n = t0 < ntile ? (ntile - t0 + G - 1) / G : 0;
+  W1Set A, B;
+  if (n > 0) {
+    issue(t0, A);
+    issue(t0 + G, B);
+    convert(t0, A, 0);
+    __syncthreads();
+    for (int i = 0; i < n; i += 2) {
+      // even step: tile i in stage 0; A is free, B holds tile i + 1
+      issue(t0 + (i + 2) * G, A);
+      mma(0);
+      convert(t0 + (i + 1) * G, B, 1);
+      __syncthreads();
+      if (i + 1 >= n) break;
+      // odd step: tile i + 1 in stage 1; B is free, A holds tile i + 2
+      issue(t0 + (i + 3) * G, B);
+      mma(1);
+      convert(t0 + (i + 2) * G, A, 0);
+      __syncthreads();
+    }
+  }
+  const int NPo = gridDim.y * 128;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = cz0 + cit * 32 + crow(r, lh);
+      p.part[((size_t)blockIdx.x * p.CINP + ci) * NPo + n0 + (nt0 + 2 * s) * 32 + li] = acc[s][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Producer / consumer form of the bf16x3 weight gradient for the multi-tap convolutions: ONE 8-wave workgroup per CU
 // with two LDS tile buffers.  Waves 0-3 (one per SIMD) only run the MFMA loop of tile t; waves 4-7 (one per SIMD) only
 // load, split and write tile t+1 into the other buffer; one barrier per tile hands the buffers over.  In
@@ -1021,6 +1179,14 @@ __global__ __launch_bounds__(1024) void reduce_partials_split_kernel(
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (e < total) {
     int g = w;
+    for (; g + 7 * S < G; g += 8 * S) {   // eight slabs in flight per lane
+      const float a0 = part[(size_t)g * total + e], a1 = part[(size_t)(g + S) * total + e];
+      const float a2 = part[(size_t)(g + 2 * S) * total + e], a3 = part[(size_t)(g + 3 * S) * total + e];
+      const float a4 = part[(size_t)(g + 4 * S) * total + e], a5 = part[(size_t)(g + 5 * S) * total + e];
+      const float a6 = part[(size_t)(g + 6 * S) * total + e], a7 = part[(size_t)(g + 7 * S) * total + e];
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+      s0 += a4; s1 += a5; s2 += a6; s3 += a7;
+    }
     for (; g + 3 * S < G; g += 4 * S) {
       s0 += part[(size_t)g * total + e];
       s1 += part[(size_t)(g + S) * total + e];
@@ -1357,12 +1523,25 @@ static bool wgrad3_pipelined(const WgradParams& P, size_t smem) {
          P.PP * (P.CC / 4) <= W3P_UX * 256 && IG_TILE_M * 8 * P.ntw <= W3P_UD * 256 && !getenv("BSED_WGRAD3_NOPIPE");
 }
 
+// the streaming 1-tap kernel takes the shapes whose slabs tile into 128 x 128 blocks (BSED_WGRAD1=0: A/B against
+// wgrad3_kernel)
+static bool wgrad1_streaming(const WgradParams& P) {
+  static const bool off = getenv("BSED_WGRAD1") && getenv("BSED_WGRAD1")[0] == '0';
+  const BsedWgradDesc& d = P.d;
+  return !off && d.ntaps == 1 && P.CC == 128 && P.ntw == 4 && d.CINP % 128 == 0 && d.NP % 128 == 0 && !d.bn_y &&
+         (long)d.NB * d.H * d.W < (1L << 31) - 4 * 65536;
+}
+
 extern "C" int bsed_wgrad3_auto_g(const BsedWgradDesc* desc) {
   WgradParams P;
   size_t smem;
   dim3 gyz;
   if (wgrad_prepare(desc, P, smem, gyz, 1) != BSED_OK) return -1;
-  const long slots = wgrad3_pipelined(P, smem) ? 256 : smem <= 80 * 1024 ? 512 : 256;
+  long slots = wgrad3_pipelined(P, smem) ? 256 : smem <= 80 * 1024 ? 512 : 256;
+  // small tiles (conv1 16 -> 32 channel gradient: 39 KB, 136 registers): a third workgroup per CU fits and hides more of
+  // the stage / barrier / MFMA serialisation: 0.956 -> 0.753 ms (four per CU: 0.913; BSED_WGRAD3_SLOTS_SMALL for A/B runs)
+  static const int small_slots = getenv("BSED_WGRAD3_SLOTS_SMALL") ? atoi(getenv("BSED_WGRAD3_SLOTS_SMALL")) : 768;
+  if (!wgrad3_pipelined(P, smem) && smem <= 52 * 1024 && wgrad_variant(P) / 16 <= 2) slots = small_slots;
   long want = std::max<long>(1, slots / ((long)gyz.y * gyz.z));
   // XCD affinity: workgroup (x, y, z) has linear id x + G * (y + gy * z) and lands on XCD id % 8.  The gy * gz
   // workgroups of one tile sequence x read the same activation / dy tiles at about the same time; with G a multiple of
@@ -1377,6 +1556,7 @@ extern "C" int bsed_wgrad3_variant(const BsedWgradDesc* desc) {
   size_t smem;
   dim3 gyz;
   if (wgrad_prepare(desc, P, smem, gyz, 1) != BSED_OK) return -1;
+  if (wgrad1_streaming(P)) return (1 << 13) | ((P.d.dh[0] != 0 || P.d.dw[0] != 0) ? 1 : 0);  // wgrad1_kernel<SHIFT>
   const int v = wgrad_variant(P);
   if (wgrad3_pipelined(P, smem)) {  // NW field 1 = wgrad3p_kernel<MAXS, GEO>, GEO in bits 8..11
     const int maxs = v / 16 <= 3 ? 3 : (v / 16 <= 5 ? 5 : 9), g = getenv("BSED_WGRAD3_NOGEO") ? 0 : wgrad3p_geo(P);
@@ -1397,6 +1577,19 @@ extern "C" int bsed_wgrad3(const BsedWgradDesc* desc, void* stream) {
   BSED_CHECK_ARG(d.G > 0 && d.G <= P.ntiles, "bsed_wgrad3: G (%d) must be in 1..%d tiles", d.G, P.ntiles);
   dim3 grid((unsigned)d.G, gyz.y, gyz.z);
   hipStream_t s = (hipStream_t)stream;
+  if (wgrad1_streaming(P)) {
+    const bool shifted = d.dh[0] != 0 || d.dw[0] != 0;
+    static BsedLdsOnce once0, once1;
+    if (shifted) {
+      BSED_HIP(bsed_max_lds(once1, (const void*)wgrad1_kernel<true>));
+      hipLaunchKernelGGL(wgrad1_kernel<true>, grid, dim3(W1_THREADS), 2 * W1_STAGE, s, P);
+    } else {
+      BSED_HIP(bsed_max_lds(once0, (const void*)wgrad1_kernel<false>));
+      hipLaunchKernelGGL(wgrad1_kernel<false>, grid, dim3(W1_THREADS), 2 * W1_STAGE, s, P);
+    }
+    BSED_LAUNCH_CHECK();
+    return BSED_OK;
+  }
   const int v = wgrad_variant(P), maxs = v / 16, nw = v % 16;
   if (wgrad3_pipelined(P, smem)) {
     if (maxs <= 3) return launch_wgrad3p<3>(P, grid, smem, s);

@@ -314,8 +314,11 @@ def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=Non
     d.part, d.G = _p(part), G
     var = getattr(L.lib(), f"bsed_wgrad{sfx}_variant")(ctypes.byref(d))
     # labels = the template instances as rocprofv3 prints them (bench.py joins the two by name)
-    bs, geo, var = var >> 12, (var >> 8) & 0xf, var & 0xff
-    if var % 16 == 1:
+    w1 = (var >> 13) & 1
+    bs, geo, var = (var >> 12) & 1, (var >> 8) & 0xf, var & 0xff
+    if w1:
+        kname = f"wgrad1_kernel<{'true' if var & 1 else 'false'}>"
+    elif var % 16 == 1:
         kname = f"wgrad3p_kernel<{var // 16}, {geo}>"
     elif sfx:
         kname = f"wgrad3_kernel<{var // 16}, {var % 16}, {'true' if bs else 'false'}>"
