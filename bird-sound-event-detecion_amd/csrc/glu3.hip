@@ -27,6 +27,7 @@
 #include "bsed_common.h"
 #include "../../include/bsed.h"
 #include <algorithm>
+#include <stdlib.h>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -807,7 +808,11 @@ static int fill_params(Glu3Params& P, int NB, int H, int W, int C, int TH, int T
 extern "C" int bsed_glu_bwd3_slabs(int C) { (void)C; return 4; }
 
 // workgroups of one resident round (persistent kernel): LDS- and register-limited occupancy x 256 CUs
-extern "C" int bsed_glu_bwd3_auto_g(int C) { return C == 32 ? 768 : 512; }
+static int env_g(const char* name, int dflt) {   // A/B knob: workgroups of the persistent grid
+  const char* v = getenv(name);
+  return v && atoi(v) > 0 ? atoi(v) : dflt;
+}
+extern "C" int bsed_glu_bwd3_auto_g(int C) { return C == 32 ? env_g("BSED_GLU_BWD3_G32", 768) : env_g("BSED_GLU_BWD3_G64", 512); }
 
 extern "C" int bsed_glu_bwd3(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
                              const float* dpool, float* g, float* part_dw, float* part_db, float* part_st, int G,
@@ -828,7 +833,11 @@ extern "C" int bsed_glu_bwd3(const float* y, const float* scale, const float* sh
   return launch_glu_bwd3<32>(P, G, s);
 }
 
-extern "C" int bsed_glu_fwd3_auto_g(int C) { (void)C; return 512; }
+extern "C" int bsed_glu_fwd3_auto_g(int C) {
+  // measured (B = 256): C = 32: 512 / 768 / 1024 / 1536 workgroups 0.447 / 0.367 / 0.412 / 0.350 ms; C = 64: 0.180 / 0.160 / 0.167 / 0.155;
+  // C = 128 (64 KB of weight fragments in LDS, two per CU): 256 / 512 / 768 / 1024 0.514 / 0.422 / 0.454 / 0.435
+  return C == 32 ? env_g("BSED_GLU_FWD3_G32", 1536) : C == 64 ? env_g("BSED_GLU_FWD3_G64", 1536) : env_g("BSED_GLU_FWD3_G128", 512);
+}
 
 extern "C" int bsed_glu_fwd3(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
                              float* pooled, int G, int NB, int H, int W, int C, int TH, int TW, int ph, int pw,

@@ -11,6 +11,7 @@
 #include "bsed_common.h"
 #include "../../include/bsed.h"
 #include <algorithm>
+#include <stdlib.h>
 
 #define I3_THREADS 256
 #define I3_M 128
@@ -538,7 +539,10 @@ extern "C" int bsed_pack_weight3s(const float* src, void* dst, int ntaps, int K,
   return BSED_OK;
 }
 
-extern "C" int bsed_igemm3s_auto_g(void) { return 1024; }
+extern "C" int bsed_igemm3s_auto_g(void) {
+  const char* v = getenv("BSED_IGEMM3S_G");   // A/B knob
+  return v && atoi(v) > 0 ? atoi(v) : 1024;
+}
 
 extern "C" int bsed_igemm3s(const BsedIgemmDesc* desc, int G, void* stream) {
   BSED_CHECK_ARG(desc, "bsed_igemm3s: null descriptor");
