@@ -468,6 +468,15 @@ extern "C" int bsed_colsum(const float* in, long M, int C, int pitch, float* par
   return bsed_stats_to_grad(part, g, C, 0, dst, accumulate, scratch, stream);
 }
 
+// the first stage alone: part (min(G, M), 2, C) per-workgroup column sums in slot 0, for a queued second stage
+// (bsed_reduce_partials_batch)
+extern "C" int bsed_colsum_part(const float* in, long M, int C, int pitch, float* part, int G, void* stream) {
+  BSED_CHECK_ARG(in && part && M > 0 && C > 0 && pitch >= C && G > 0 && G <= M, "bsed_colsum_part: bad argument");
+  hipLaunchKernelGGL(colsum_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, in, M, C, pitch, part);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
 extern "C" int bsed_dropout(const float* in, float* out, long n, float p, uint32_t rng_stream, uint64_t seed,
                             void* stream) {
   BSED_CHECK_ARG(in && out && n > 0 && p >= 0.f && p < 1.f, "bsed_dropout: bad argument");

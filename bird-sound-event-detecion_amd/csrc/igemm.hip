@@ -1210,6 +1210,64 @@ __global__ __launch_bounds__(1024) void reduce_partials_split_kernel(
   }
 }
 
+// Up to BSED_REDUCE_MAX_JOBS partial-slab reductions in ONE launch.  A training step ends ~30 contractions with such a
+// reduction (weight gradients, bias gradients), each a 10-12 us launch for microseconds of work: the results are only
+// needed by the optimizer (or the gradient all-reduce), so the host queues them and flushes the queue once.  A
+// workgroup (16 waves) owns 64 * (16 / S) consecutive elements of one job and its waves split that job's slabs S ways
+// (S = 16 for the smallest outputs); partial sums are combined through LDS in a fixed order: deterministic.
+struct RpJob {
+  const float* part; float* dst;
+  int G, KP, NP, K, N, S, accumulate, wg0;   // wg0 = first workgroup of this job
+  long total, s_tap, s_k, s_n;
+};
+struct RpBatch { RpJob j[BSED_REDUCE_MAX_JOBS]; int njobs; };
+
+__global__ __launch_bounds__(1024) void reduce_partials_batch_kernel(const RpBatch Bt) {
+  __shared__ float red[16][64];
+  int ji = 0;
+  for (int k = 1; k < Bt.njobs; ++k)
+    if ((int)blockIdx.x >= Bt.j[k].wg0) ji = k;
+  const RpJob& J = Bt.j[ji];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, S = J.S;
+  const int sub = w / S, ws = w % S;             // 16 / S element groups per workgroup, S slab shares each
+  const long total = J.total;
+  const long e = ((long)(blockIdx.x - J.wg0) * (16 / S) + sub) * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < total) {
+    const float* part = J.part;
+    const int G = J.G;
+    int g = ws;
+    for (; g + 7 * S < G; g += 8 * S) {   // eight slabs in flight per lane
+      const float a0 = part[(size_t)g * total + e], a1 = part[(size_t)(g + S) * total + e];
+      const float a2 = part[(size_t)(g + 2 * S) * total + e], a3 = part[(size_t)(g + 3 * S) * total + e];
+      const float a4 = part[(size_t)(g + 4 * S) * total + e], a5 = part[(size_t)(g + 5 * S) * total + e];
+      const float a6 = part[(size_t)(g + 6 * S) * total + e], a7 = part[(size_t)(g + 7 * S) * total + e];
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+      s0 += a4; s1 += a5; s2 += a6; s3 += a7;
+    }
+    for (; g + 3 * S < G; g += 4 * S) {   // (same assignment of slabs to the four sums as bsed_reduce_partials:
+      s0 += part[(size_t)g * total + e];  //  a queued and an immediate reduction give the same bits)
+      s1 += part[(size_t)(g + S) * total + e];
+      s2 += part[(size_t)(g + 2 * S) * total + e];
+      s3 += part[(size_t)(g + 3 * S) * total + e];
+    }
+    for (; g < G; g += S) s0 += part[(size_t)g * total + e];
+  }
+  red[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ws == 0 && e < total) {
+    float s = red[w][lane];
+    for (int i = 1; i < S; ++i) s += red[w + i][lane];
+    const int n = (int)(e % J.NP);
+    const long r = e / J.NP;
+    const int k = (int)(r % J.KP), tap = (int)(r / J.KP);
+    if (n < J.N && k < J.K) {
+      float* d = J.dst + tap * J.s_tap + k * J.s_k + n * J.s_n;
+      *d = J.accumulate ? *d + s : s;
+    }
+  }
+}
+
 // wpk[tap][k][n] = src[tap*s_tap + k*s_k + n*s_n], zero for n >= N
 __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int ntaps, int K, int N,
                                    int NP, long s_tap, long s_k, long s_n) {
@@ -1623,6 +1681,37 @@ extern "C" int bsed_reduce_partials(const float* part, int G, int ntaps, int KP,
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)std::min<long>(ceil_div(total, 256), 4096)), dim3(256), 0,
                      (hipStream_t)stream, part, G, ntaps, KP, NP, K, N, dst, s_tap, s_k, s_n, accumulate);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_reduce_partials_batch(const BsedReduceJob* jobs, int njobs, void* stream) {
+  BSED_CHECK_ARG(jobs && njobs > 0 && njobs <= BSED_REDUCE_MAX_JOBS, "bsed_reduce_partials_batch: 1..%d jobs",
+                 BSED_REDUCE_MAX_JOBS);
+  RpBatch Bt;
+  Bt.njobs = njobs;
+  long wg = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const BsedReduceJob& q = jobs[i];
+    BSED_CHECK_ARG(q.part && q.dst && q.G > 0 && q.ntaps > 0 && q.KP >= q.K && q.NP >= q.N && q.K > 0 && q.N > 0,
+                   "bsed_reduce_partials_batch: bad job %d", i);
+    for (int k = 0; k < i; ++k)
+      BSED_CHECK_ARG(jobs[k].dst != q.dst, "bsed_reduce_partials_batch: jobs %d and %d write the same destination "
+                     "(flush between them)", k, i);
+    RpJob& J = Bt.j[i];
+    J.part = q.part; J.dst = q.dst; J.G = q.G; J.KP = q.KP; J.NP = q.NP; J.K = q.K; J.N = q.N;
+    J.accumulate = q.accumulate; J.s_tap = q.s_tap; J.s_k = q.s_k; J.s_n = q.s_n;
+    J.total = (long)q.ntaps * q.KP * q.NP;
+    const long chunks = ceil_div(J.total, 64);   // 64-element groups
+    int S = 1;
+    if (chunks < 1024 && q.G >= 8)   // the split rule of bsed_reduce_partials
+      while (S < 16 && chunks * S < 1024 && 4 * S <= q.G) S *= 2;
+    J.S = S;
+    J.wg0 = (int)wg;
+    wg += ceil_div(chunks, 16 / S);
+    BSED_CHECK_ARG(wg < (1L << 31), "bsed_reduce_partials_batch: too many workgroups");
+  }
+  hipLaunchKernelGGL(reduce_partials_batch_kernel, dim3((unsigned)wg), dim3(1024), 0, (hipStream_t)stream, Bt);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }

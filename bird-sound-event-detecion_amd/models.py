@@ -425,7 +425,7 @@ class CRNN(_FlatModule):
             if self.overlap_rnn:
                 main, side = torch.cuda.current_stream(), self._side()
                 side.wait_stream(main)                      # dxp / dgh (and the zeroed gradient arena) are ready
-                with torch.cuda.stream(side):
+                with torch.cuda.stream(side), ops.deferred_reductions():   # the side stream's own queue: same kernels
                     self._gru_param_grads(lay, l, prefix, dxp, dgh, pih, phh, B, T)
                 for t in (dxp, dgh, pih, phh, lay["inp"], lay["out"]):
                     if t is not None:
@@ -579,6 +579,7 @@ class CRNN(_FlatModule):
             if i == min(self.TAIL_BLOCKS, len(self.nb_filters)) - 1:
                 self._join_side()      # the GRU weight gradients (side stream) belong to the early segment
                 if on_early_grads is not None:
+                    ops.flush_reductions()   # ... and the queued reductions that finish them
                     on_early_grads()   # every gradient outside the first TAIL_BLOCKS blocks has been enqueued
             dpool = self._block_backward(ctx["blocks"][i], dpool, ctx["B"], ctx["seed"])
 
@@ -605,15 +606,18 @@ class CRNN(_FlatModule):
         (the data-parallel trainer starts its gradient all-reduce there, overlapping the rest of the backward pass)."""
         B, T = ctx["B"], ctx["T"]
         d = d_enc.contiguous()
-        if ctx["drop"] > 0:
-            d = ops.dropout(d, ctx["drop"], 200, ctx["seed"])
-        d = self._gru_backward(ctx["layers"], d, B, T, "rnn")
-        if not self.train_cnn:
-            self._join_side()
-            if on_early_grads is not None:
-                on_early_grads()
-            return
-        self._cnn_backward(ctx, d.view(B, T, 1, self.nb_filters[-1]), on_early_grads)
+        # weight / bias gradient reductions are queued and go out in one launch per flush (ops.deferred_reductions)
+        with ops.deferred_reductions():
+            if ctx["drop"] > 0:
+                d = ops.dropout(d, ctx["drop"], 200, ctx["seed"])
+            d = self._gru_backward(ctx["layers"], d, B, T, "rnn")
+            if not self.train_cnn:
+                self._join_side()
+                ops.flush_reductions()
+                if on_early_grads is not None:
+                    on_early_grads()
+                return
+            self._cnn_backward(ctx, d.view(B, T, 1, self.nb_filters[-1]), on_early_grads)
 
     def forward(self, x):
         if torch.is_grad_enabled() and self.training:
@@ -740,6 +744,10 @@ class CRNN_fpn(CRNN):
         return enc, ctx
 
     def run_backward(self, ctx, d_enc, on_early_grads=None):
+        with ops.deferred_reductions():
+            return self._run_backward_fpn(ctx, d_enc, on_early_grads)
+
+    def _run_backward_fpn(self, ctx, d_enc, on_early_grads):
         B, T, T2, T4 = ctx["B"], ctx["T"], ctx["T2"], ctx["T4"]
         seed, drop = ctx["seed"], ctx["drop"]
         C = self.nb_filters[-1]
@@ -757,6 +765,7 @@ class CRNN_fpn(CRNN):
             d_seq.append(self._gru_backward(layers, d, B, Tl, pfx))
         if not self.train_cnn:
             self._join_side()
+            ops.flush_reductions()
             if on_early_grads is not None:
                 on_early_grads()
             return

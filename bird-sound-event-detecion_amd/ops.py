@@ -331,7 +331,69 @@ def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=Non
     return part, G, CINP, NP
 
 
+class ReduceJob(ctypes.Structure):
+    _fields_ = ([("part", _fp), ("dst", _fp)]
+                + [(n, _i) for n in ("G", "ntaps", "KP", "NP", "K", "N", "accumulate")]
+                + [(n, ctypes.c_long) for n in ("s_tap", "s_k", "s_n")])
+
+
+REDUCE_MAX_JOBS = 40
+_rq = None   # the active queue of deferred reductions: dict(stream=..., jobs=[(ReduceJob fields..., keepalive)])
+
+
+class deferred_reductions:
+    """Inside this block the partial-slab reductions whose results nothing in the block reads (weight and bias
+    gradients: only the optimizer / the gradient all-reduce need them) are queued instead of launched, and go out
+    together -- one bsed_reduce_partials_batch launch per flush instead of ~30 launches of 10 us each.  flush() in the
+    middle publishes everything queued so far (the data-parallel trainer does that before its early all-reduce).
+    Reductions issued on another stream than the one the block was opened on run immediately."""
+
+    def __enter__(self):
+        global _rq
+        self._outer = _rq
+        _rq = {"stream": L.stream().value, "jobs": []}
+        return self
+
+    def __exit__(self, *exc):
+        global _rq
+        try:
+            if exc[0] is None:
+                flush_reductions()
+        finally:
+            _rq = self._outer
+        return False
+
+
+def flush_reductions():
+    """launch what the active queue holds (jobs writing the same destination go to successive launches, in order)"""
+    if _rq is None or not _rq["jobs"]:
+        return
+    pending, _rq["jobs"] = _rq["jobs"], []
+    while pending:
+        batch, rest, seen = [], [], set()
+        for job in pending:
+            key = job[1]
+            if key in seen or len(batch) == REDUCE_MAX_JOBS or rest:
+                rest.append(job)          # keep the order of everything behind the first job that has to wait
+            else:
+                seen.add(key)
+                batch.append(job)
+        arr = (ReduceJob * len(batch))()
+        nel = 0
+        for i, (part, dst_ptr, G, ntaps, KP, NP, K, N, s_tap, s_k, s_n, acc) in enumerate(batch):
+            arr[i].part, arr[i].dst = part.data_ptr(), dst_ptr
+            arr[i].G, arr[i].ntaps, arr[i].KP, arr[i].NP, arr[i].K, arr[i].N = G, ntaps, KP, NP, K, N
+            arr[i].accumulate, arr[i].s_tap, arr[i].s_k, arr[i].s_n = acc, s_tap, s_k, s_n
+            nel += part.numel()
+        _note("reduce_partials_batch_kernel", f"jobs{len(batch)}", float(nel), 4.0 * nel)
+        L.call("bsed_reduce_partials_batch", arr, _i(len(batch)), L.stream())
+        pending = rest
+
+
 def reduce_partials(part, G, ntaps, KP, NP, K, N, dst, s_tap, s_k, s_n, accumulate=True, dst_offset=0):
+    if _rq is not None and _rq["stream"] == L.stream().value:
+        _rq["jobs"].append((part, _dp(dst, dst_offset), G, ntaps, KP, NP, K, N, s_tap, s_k, s_n, 1 if accumulate else 0))
+        return
     _note("reduce_partials_kernel", f"G{G}", float(part.numel()), 4.0 * part.numel())
     L.call("bsed_reduce_partials", L.ptr(part), _i(G), _i(ntaps), _i(KP), _i(NP), _i(K), _i(N),
            _fp(_dp(dst, dst_offset)), ctypes.c_long(s_tap), ctypes.c_long(s_k), ctypes.c_long(s_n),
@@ -578,6 +640,10 @@ def bn_bwd(stats, C, count, gamma, mean, invstd, dgamma, dbeta, g_inout, y, appl
 
 
 def stats_to_grad(stats, C, which, dst):
+    if _rq is not None and _rq["stream"] == L.stream().value and which == 0 and stats.dim() == 3 and stats.shape[1] == 2:
+        # row 0 of every (2, C) partial: a queued slab reduction with K = 1 of KP = 2 rows (fp32 sums, fixed order)
+        _rq["jobs"].append((stats, _dp(dst), stats.shape[0], 1, 2, C, 1, C, 0, 0, 1, 1))
+        return
     _note("stats_chunk_kernel+stats_finish_kernel", f"C{C}", 0.0, 4.0 * stats.numel())
     L.call("bsed_stats_to_grad", L.ptr(stats), ctypes.c_long(stats.shape[0]), _i(C), _i(which), _fp(_dp(dst)), _i(1),
            L.ptr(stats_scratch(C, stats.device), torch.float64), L.stream())
@@ -587,6 +653,11 @@ def colsum(inp, M, C, pitch, dst, accumulate=True, in_offset=0):
     G = int(min(512, M))
     part = torch.empty((G, 2, C), device=inp.device, dtype=torch.float32)
     _note("colsum_kernel", f"C{C}", float(M) * C, 4.0 * M * C)
+    if _rq is not None and _rq["stream"] == L.stream().value:
+        L.call("bsed_colsum_part", _fp(_dp(inp, in_offset)), ctypes.c_long(M), _i(C), _i(pitch), L.ptr(part), _i(G),
+               L.stream())
+        _rq["jobs"].append((part, _dp(dst), G, 1, 2, C, 1, C, 0, 0, 1, 1 if accumulate else 0))
+        return
     L.call("bsed_colsum", _fp(_dp(inp, in_offset)), ctypes.c_long(M), _i(C), _i(pitch), L.ptr(part), _i(G),
            _fp(_dp(dst)), _i(1 if accumulate else 0), L.ptr(stats_scratch(C, inp.device), torch.float64), L.stream())
 

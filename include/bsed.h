@@ -169,6 +169,15 @@ int bsed_wgrad3_variant(const BsedWgradDesc* desc /*host*/);
 /* dst[tap*s_tap + k*s_k + n*s_n] (+)= sum_g part[g][tap][k][n]   (k < K, n < N) */
 int bsed_reduce_partials(const float* part, int G, int ntaps, int KP, int NP, int K, int N, float* dst,
                          long s_tap, long s_k, long s_n, int accumulate, void* stream);
+/* several bsed_reduce_partials in one launch (the host queues the reductions whose results only the optimizer needs
+ * and flushes them together): same arithmetic contract per job, jobs of one call must write distinct destinations */
+#define BSED_REDUCE_MAX_JOBS 40
+typedef struct BsedReduceJob {
+  const float* part; float* dst;
+  int G, ntaps, KP, NP, K, N, accumulate;
+  long s_tap, s_k, s_n;
+} BsedReduceJob;
+int bsed_reduce_partials_batch(const BsedReduceJob* jobs /*host*/, int njobs, void* stream);
 /* dst[tap][k][n] = src[tap*s_tap + k*s_k + n*s_n], zero for N <= n < NP */
 int bsed_pack_weight(const float* src, float* dst, int ntaps, int K, int N, int NP, long s_tap, long s_k,
                      long s_n, void* stream);
@@ -211,6 +220,9 @@ int bsed_stats_to_grad(const float* partial, long ntiles, int C, int which, floa
 /* dst[c] (+)= sum_r in[r*pitch + c], r < M; part holds G*2*C floats */
 int bsed_colsum(const float* in, long M, int C, int pitch, float* part, int G, float* dst, int accumulate,
                 void* scratch, void* stream);
+/* first stage of bsed_colsum alone: part (G, 2, C), G <= M, slot 0 = per-workgroup column sums (second stage: a
+ * bsed_reduce_partials_batch job with KP = 2, K = 1) */
+int bsed_colsum_part(const float* in, long M, int C, int pitch, float* part, int G, void* stream);
 /* nn.Dropout(p) with a stateless Philox mask: out = in * keep/(1-p); the same call is its backward */
 int bsed_dropout(const float* in, float* out, long n, float p, uint32_t rng_stream, uint64_t seed, void* stream);
 
