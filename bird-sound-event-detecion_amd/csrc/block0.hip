@@ -27,17 +27,6 @@
 #define B0_C 16
 #define B0_NXR 54   // Sx[9] then R packed upper triangle (t <= t'): 45
 
-struct B0W { float w[4][9]; float b[4]; };   // conv taps and bias of the lane's four channels
-
-__device__ __forceinline__ void b0_load_w(const float* __restrict__ cw, const float* __restrict__ cb, int q, B0W& K) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int t = 0; t < 9; ++t) K.w[i][t] = cw[(4 * q + i) * 9 + t];
-    K.b[i] = cb[4 * q + i];
-  }
-}
-
 // THE definition of y0: bias, then taps 0..8 in order, one fma each (conv0_fwd_kernel uses the same chain)
 __device__ __forceinline__ float b0_conv1(const float (&x9)[9], const float (&w)[9], float b) {
   float a = b;
@@ -45,8 +34,6 @@ __device__ __forceinline__ float b0_conv1(const float (&x9)[9], const float (&w)
   for (int t = 0; t < 9; ++t) a = fmaf(x9[t], w[t], a);
   return a;
 }
-
-__device__ float b0_sink[256];
 
 __device__ __forceinline__ f32x4 b0_mm16(const float (&a)[4], float b0, float b1, float b2, float b3, f32x4 c) {
   asm volatile("s_nop 4" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(c));
@@ -112,7 +99,10 @@ struct B0Idx {
 // statistics: one position per thread, persistent over (image, 2-row strips); 16 + 16 + 54 thread-private sums
 // ---------------------------------------------------------------------------------------------
 #define B0S_THREADS 256
-__global__ __launch_bounds__(B0S_THREADS) void b0_stats_kernel(const float* __restrict__ x, const float* __restrict__ cw,
+// cwt = the conv weight TRANSPOSED, [tap][channel]: the channels of one tap are then consecutive scalar registers and
+// a pair of them is one operand of v_pk_fma_f32 (two channels per instruction; with the (16,1,3,3) layout the compiler
+// packed over channels all the same and paid ~200 v_mov per position to build the pairs: 0.26 -> 0.13 ms)
+__global__ __launch_bounds__(B0S_THREADS) void b0_stats_kernel(const float* __restrict__ x, const float* __restrict__ cwt,
                                                                const float* __restrict__ cb, float* __restrict__ stats,
                                                                float* __restrict__ xr, int NB, int H, int W) {
   __shared__ float red[B0S_THREADS * 9];
@@ -144,7 +134,7 @@ __global__ __launch_bounds__(B0S_THREADS) void b0_stats_kernel(const float* __re
     for (int c = 0; c < B0_C; ++c) {
       float wv[9];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) wv[t] = cw[c * 9 + t];   // wave-uniform: scalar loads, SGPR operands
+      for (int t = 0; t < 9; ++t) wv[t] = cwt[t * B0_C + c];   // wave-uniform: scalar loads, SGPR-pair operands
       const float y = b0_conv1(x9, wv, cb[c]);
       sy[c] += y;
       sq[c] = fmaf(y, y, sq[c]);
@@ -566,14 +556,14 @@ __global__ __launch_bounds__(256) void b0_wgrad_finish_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
-extern "C" int bsed_block0_stats(const float* x, const float* cw, const float* cb, float* stats, float* xr_part,
+extern "C" int bsed_block0_stats(const float* x, const float* cw_t, const float* cb, float* stats, float* xr_part,
                                  double* xr64, int G, int NB, int H, int W, int CO, void* stream) {
-  BSED_CHECK_ARG(x && cw && cb && stats && xr_part && xr64, "bsed_block0_stats: null tensor");
+  BSED_CHECK_ARG(x && cw_t && cb && stats && xr_part && xr64, "bsed_block0_stats: null tensor");
   BSED_CHECK_ARG(CO == B0_C, "bsed_block0_stats: built for 16 first-layer channels (got %d)", CO);
   BSED_CHECK_ARG(G > 0 && NB > 0 && H > 0 && W > 0 && W <= 256 && (long)NB * H < (1L << 30),
                  "bsed_block0_stats: bad shape (W <= 256)");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(b0_stats_kernel, dim3(G), dim3(B0S_THREADS), 0, s, x, cw, cb, stats, xr_part, NB, H, W);
+  hipLaunchKernelGGL(b0_stats_kernel, dim3(G), dim3(B0S_THREADS), 0, s, x, cw_t, cb, stats, xr_part, NB, H, W);
   hipLaunchKernelGGL(b0_colsum64_kernel, dim3(ceil_div(B0_NXR, 4)), dim3(256), 0, s, xr_part, G, B0_NXR, xr64);
   BSED_LAUNCH_CHECK();
   return BSED_OK;

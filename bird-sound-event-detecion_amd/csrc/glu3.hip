@@ -46,6 +46,11 @@ struct Glu3Params {
   float drop_p; uint32_t rng_stream; uint64_t seed;
 };
 
+static bool glu3_const_tw(const Glu3Params& P) {   // BSED_GLU3_LGTW=-1: runtime-geometry instances only (A/B runs)
+  static const bool off = getenv("BSED_GLU3_LGTW") && atoi(getenv("BSED_GLU3_LGTW")) < 0;
+  return P.lgTW == 4 && !off;
+}
+
 // Orders this wave's LDS writes before its later LDS reads.  The hardware executes one wave's LDS instructions in
 // issue order, but the COMPILER may move a 16-byte fragment load above the 2-byte element stores that produce it (type
 // based alias analysis sees unrelated types; __builtin_amdgcn_wave_barrier() does not order memory operations).
@@ -108,11 +113,11 @@ __device__ __forceinline__ void build_weight_frags(const float* __restrict__ w, 
 
 // GEMM1 A fragments of this wave's 32 positions: BatchNorm-applied, split
 template <int C>
-__device__ __forceinline__ void load_a_frags(const Glu3Params& P, const float* s_sc, const float* s_sh, int nb, int th0,
-                                             int tw0, int wave, int li, int lh, bf16x8* a_hi, bf16x8* a_lo) {
+__device__ __forceinline__ void load_a_frags(const Glu3Params& P, int lgTW, const float* s_sc, const float* s_sh, int nb,
+                                             int th0, int tw0, int wave, int li, int lh, bf16x8* a_hi, bf16x8* a_lo) {
   constexpr int KS = C / 16;
   const int mA = wave * 32 + li;
-  const int gh = th0 + (mA >> P.lgTW), gw = tw0 + (mA & (P.TW - 1));
+  const int gh = th0 + (mA >> lgTW), gw = tw0 + (mA & ((1 << lgTW) - 1));
   const bool ok = gh < P.H;
   const float* rp = P.y + (((size_t)nb * P.H + (ok ? gh : 0)) * P.W + gw) * C + 8 * lh;
   float4 raw[KS][2];
@@ -145,9 +150,15 @@ __device__ __forceinline__ float drop_mul32(uint32_t e, uint32_t key, uint32_t t
   return (h >> 8) >= thr ? scale : 0.f;
 }
 
-template <int C>
+template <int C, int LGTW>
 __global__ __launch_bounds__(G3_THREADS, C == 32 ? 3 : 2) void glu_bwd3_kernel(const Glu3Params P) {
   constexpr int NT = C / 32, KS = C / 16;
+  // LGTW >= 0: the tile width is a compile-time constant (16 for every block of the reference network with more than
+  // 8 frequency bins), so the per-row index arithmetic of the epilogues -- (m >> lgTW, m & (TW - 1)) of 16 rows per
+  // lane, with their clamps, pooling indices and dropout counters: ~600 of the ~1400 instructions of a tile at
+  // C = 32 -- folds into constants plus a lane term
+  const int lgTW = LGTW >= 0 ? LGTW : P.lgTW;
+  const int TWc = 1 << lgTW, THc = G3_M >> lgTW;
   constexpr int DP = 2 * C + 8;  // ushorts per row of the d_lin tile: C hi | C lo | 8 pad ((2C+8)*2 B = odd x 16 B)
   extern __shared__ __align__(16) unsigned char smem_raw[];
   bf16x8* WF = reinterpret_cast<bf16x8*>(smem_raw);
@@ -185,17 +196,17 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? 3 : 2) void glu_bwd3_kernel(c
     const int tw_i = tile % P.tilesW; tile /= P.tilesW;
     const int th_i = tile % P.tilesH;
     const int nb = tile / P.tilesH;
-    const int th0 = th_i * P.TH, tw0 = tw_i * P.TW;
+    const int th0 = th_i * THc, tw0 = tw_i * TWc;
     // opaque copy of the lane's row offset: keeps the per-row index arithmetic of the epilogues (16 rows x several
     // values, all tile-invariant) from being hoisted out of the tile loop into ~40 long-lived registers
     int lhv = 4 * lh;
-    asm volatile("" : "+v"(lhv));
+    if (LGTW < 0) asm volatile("" : "+v"(lhv));
 
     // ---- GEMM1: lin = xn W^T
     f32x16 acc[NT];
     {
       bf16x8 a_hi[KS], a_lo[KS];
-      load_a_frags<C>(P, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
+      load_a_frags<C>(P, lgTW, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? 3 : 2) void glu_bwd3_kernel(c
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int mm = wave * 32 + 8 * rg + lhv + rr;
-          const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (P.TW - 1));
+          const int gh = th0 + (mm >> lgTW), gw = tw0 + (mm & (TWc - 1));
           const int gph = gh >> sph, gpw = gw >> spw;
           mk[rr] = (gh < P.H && gph < P.Hp && gpw < P.Wp) ? inv_pool : 0.f;
           posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? 3 : 2) void glu_bwd3_kernel(c
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int mm = wave * 32 + 8 * rg + lhv + rr;
-        const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (P.TW - 1));
+        const int gh = th0 + (mm >> lgTW), gw = tw0 + (mm & (TWc - 1));
         okf[rr] = gh < P.H ? 1.0f : 0.0f;
         posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
         gdst[rr] = gh < P.H ? P.g + posv[rr] : g3_sink + li;  // rows below the image store to a sink: no branch
@@ -397,6 +408,10 @@ __global__ void glu3_pack_frags_kernel(const float* __restrict__ w, bf16x8* __re
 __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params P, const bf16x8* __restrict__ table,
                                                                 float* __restrict__ dlin) {
   constexpr int C = 128, NT = 4, KS = 8;
+  // (runtime tile geometry, read from the parameter block exactly as in round 1, on purpose: builds of this kernel
+  // whose geometry was a compile-time constant or was derived from P.lgTW by shifts were NOT bitwise repeatable on
+  // MI355X -- whole elements of g / d_lin changed between two runs, with every tolerance-based test green -- while
+  // this source is; tests/test_glu_repeat_gpu.py guards every instance that is built)
   constexpr int DQ = 2 * 16 + 8;  // ushorts per row of the 16-channel chunk tile: 16 hi | 16 lo | 8 pad (80 B = 5 x 16 B)
   extern __shared__ __align__(16) unsigned char smem_raw[];
   bf16x8* WF = reinterpret_cast<bf16x8*>(smem_raw);
@@ -438,7 +453,7 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
     f32x16 acc[NT];
     {
       bf16x8 a_hi[KS], a_lo[KS];
-      load_a_frags<C>(P, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
+      load_a_frags<C>(P, P.lgTW, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -591,9 +606,15 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
 // GEMM1 as above; the epilogue works in the C layout where a lane holds, for its channel, four consecutive positions
 // per register group: the (1,2) and (2,2) pooling windows of a tile row are lane-local (the vertical partner of a
 // position sits 8 registers further at TW = 16, 4 at TW = 8, 2 at TW = 2), so pooling needs neither LDS nor shuffles.
-template <int C>
+template <int C, int LGTW>
 __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Params P) {
   constexpr int NT = C / 32, KS = C / 16;
+  // LGTW >= 0: the tile width is a compile-time constant (16 for every block of the reference network with more than
+  // 8 frequency bins), so the per-row index arithmetic of the epilogues -- (m >> lgTW, m & (TW - 1)) of 16 rows per
+  // lane, with their clamps, pooling indices and dropout counters: ~600 of the ~1400 instructions of a tile at
+  // C = 32 -- folds into constants plus a lane term
+  const int lgTW = LGTW >= 0 ? LGTW : P.lgTW;
+  const int TWc = 1 << lgTW, THc = G3_M >> lgTW;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   bf16x8* WF = reinterpret_cast<bf16x8*>(smem_raw);
   float* s_sc = reinterpret_cast<float*>(WF + NT * KS * 2 * 64);
@@ -616,7 +637,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
   const uint32_t dkey = drop_key(P.rng_stream, P.seed), dthr = drop_threshold(P.drop_p);
   const float dscale = P.drop_p > 0.f ? 1.0f / (1.0f - P.drop_p) : 1.0f;
   // register distance of the vertical pooling partner (position m + TW): crow(r + dr) = crow(r) + TW
-  const int TW = P.TW;
+  const int TW = TWc;
   float bias[NT], csc[NT], csh[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -629,7 +650,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
     const int tw_i = tile % P.tilesW; tile /= P.tilesW;
     const int th_i = tile % P.tilesH;
     const int nb = tile / P.tilesH;
-    const int th0 = th_i * P.TH, tw0 = tw_i * P.TW;
+    const int th0 = th_i * THc, tw0 = tw_i * TWc;
     int lhv = 4 * lh;
     if (C > 64) asm volatile("" : "+v"(lhv));  // C <= 64 have registers to spare: let the per-row index math be hoisted
 
@@ -643,7 +664,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
         for (int k = 0; k < NL; ++k) {
           const int e = lane + 64 * k, pr = e / Q, q = e % Q;
           const int mm = wave * 32 + pr;
-          const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (TW - 1));
+          const int gh = th0 + (mm >> lgTW), gw = tw0 + (mm & (TW - 1));
           raw[k] = gh < P.H ? *reinterpret_cast<const f32x4*>(P.y + (((size_t)nb * P.H + gh) * P.W + gw) * C + 4 * q)
                             : f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -655,7 +676,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // image complete before other lanes' rows are read
         const int mA = wave * 32 + li;
-        const float okf = th0 + (mA >> P.lgTW) < P.H ? 1.0f : 0.0f;
+        const float okf = th0 + (mA >> lgTW) < P.H ? 1.0f : 0.0f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const f32x4 r0 = *reinterpret_cast<const f32x4*>(Ys + li * YROW + 16 * ks + 8 * lh);
@@ -672,7 +693,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
           split_pack8(v, a_hi[ks], a_lo[ks]);
         }
       } else {
-        load_a_frags<C>(P, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
+        load_a_frags<C>(P, lgTW, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j)
@@ -698,7 +719,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int mm = wave * 32 + 8 * rg + lhv + rr;
-        const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (TW - 1));
+        const int gh = th0 + (mm >> lgTW), gw = tw0 + (mm & (TW - 1));
         mk[rr] = gh < P.H ? 1.0f : 0.0f;
         posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
 #pragma unroll
@@ -722,7 +743,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
       for (int r = 0; r < 16; ++r) {
         if (P.pw == 2 && (r & 1)) continue;
         const int mm = wave * 32 + crow3g(r, 0) + lhv;
-        const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (TW - 1));
+        const int gh = th0 + (mm >> lgTW), gw = tw0 + (mm & (TW - 1));
         const int gpw = gw >> spw;
         if (gh < P.H && gpw < P.Wp) {
           float* dst = P.pooled + (((size_t)nb * P.Hp + gh) * P.Wp + gpw) * C + li;
@@ -739,7 +760,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int mm = wave * 32 + crow3g(r, 0) + lhv;
-        const int lr = mm >> P.lgTW;  // tile row
+        const int lr = mm >> lgTW;  // tile row
         const int gh = th0 + lr, gw = tw0 + (mm & (TW - 1));
         const int gph = gh >> 1, gpw = gw >> spw;
         const bool top = (lr & 1) == 0 && (P.pw == 1 || (gw & 1) == 0);
@@ -766,9 +787,14 @@ static int launch_glu_fwd3(const Glu3Params& P, int G, hipStream_t s) {
   constexpr int NT = C / 32, KS = C / 16;
   const size_t smem = (size_t)NT * KS * 2 * 64 * 16 + 2 * C * sizeof(float) +
                       (C <= 64 ? (size_t)4 * 32 * (C + 4) * sizeof(float) : 0);  // + the waves' staged y rows
-  static BsedLdsOnce once;
-  BSED_HIP(bsed_max_lds(once, (const void*)glu_fwd3_kernel<C>));
-  hipLaunchKernelGGL((glu_fwd3_kernel<C>), dim3(G), dim3(G3_THREADS), smem, s, P);
+  static BsedLdsOnce once, once4;
+  if (glu3_const_tw(P)) {
+    BSED_HIP(bsed_max_lds(once4, (const void*)glu_fwd3_kernel<C, 4>));
+    hipLaunchKernelGGL((glu_fwd3_kernel<C, 4>), dim3(G), dim3(G3_THREADS), smem, s, P);
+  } else {
+    BSED_HIP(bsed_max_lds(once, (const void*)glu_fwd3_kernel<C, -1>));
+    hipLaunchKernelGGL((glu_fwd3_kernel<C, -1>), dim3(G), dim3(G3_THREADS), smem, s, P);
+  }
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }
@@ -782,9 +808,14 @@ static size_t glu_bwd3_smem() {
 template <int C>
 static int launch_glu_bwd3(const Glu3Params& P, int G, hipStream_t s) {
   const size_t smem = glu_bwd3_smem<C>();
-  static BsedLdsOnce once;
-  BSED_HIP(bsed_max_lds(once, (const void*)glu_bwd3_kernel<C>));
-  hipLaunchKernelGGL((glu_bwd3_kernel<C>), dim3(G), dim3(G3_THREADS), smem, s, P);
+  static BsedLdsOnce once, once4;
+  if (glu3_const_tw(P)) {
+    BSED_HIP(bsed_max_lds(once4, (const void*)glu_bwd3_kernel<C, 4>));
+    hipLaunchKernelGGL((glu_bwd3_kernel<C, 4>), dim3(G), dim3(G3_THREADS), smem, s, P);
+  } else {
+    BSED_HIP(bsed_max_lds(once, (const void*)glu_bwd3_kernel<C, -1>));
+    hipLaunchKernelGGL((glu_bwd3_kernel<C, -1>), dim3(G), dim3(G3_THREADS), smem, s, P);
+  }
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }

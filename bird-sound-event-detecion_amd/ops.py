@@ -471,7 +471,8 @@ def block0_stats(x, cw, cb, NB, H, W):
     xr_part = torch.empty((G, 54), device=dev, dtype=torch.float32)
     xr64 = torch.empty(54, device=dev, dtype=torch.float64)
     _note("b0_stats_kernel", f"{H}x{W}", 2.0 * NB * H * W * (9 * 16 + 16 + 54), 4.0 * NB * H * W)
-    L.call("bsed_block0_stats", L.ptr(x), _fp(_dp(cw)), _fp(_dp(cb)), L.ptr(stats), L.ptr(xr_part),
+    cwt = cw.detach().reshape(16, 9).t().contiguous()   # [tap][channel]: channel pairs become packed scalar operands
+    L.call("bsed_block0_stats", L.ptr(x), L.ptr(cwt), _fp(_dp(cb)), L.ptr(stats), L.ptr(xr_part),
            L.ptr(xr64, torch.float64), _i(G), _i(NB), _i(H), _i(W), _i(16), L.stream())
     return stats, xr64
 
@@ -546,7 +547,7 @@ def glu_fwd3(y, scale, shift, w, bias, B, H, W, C, pool, drop_p, rng_stream, see
     ntiles = B * ((H + TH - 1) // TH) * (W // TW)
     G = int(min(ntiles, L.lib().bsed_glu_fwd3_auto_g(C)))
     out = torch.empty((B, H // ph, W // pw, C), device=y.device, dtype=torch.float32)
-    _launch((f"glu_fwd3_kernel<{C}>", 1, C, C, H, W), 2.0 * B * H * W * C * C,
+    _launch((f"glu_fwd3_kernel<{C}, {4 if TW == 16 else -1}>", 1, C, C, H, W), 2.0 * B * H * W * C * C,
             lambda: L.call("bsed_glu_fwd3", L.ptr(y), L.ptr(scale), L.ptr(shift), _fp(_dp(w)), _fp(_dp(bias)),
                            L.ptr(out), _i(G), _i(B), _i(H), _i(W), _i(C), _i(TH), _i(TW), _i(ph), _i(pw),
                            ctypes.c_float(drop_p), ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream()),
@@ -567,7 +568,7 @@ def glu_bwd3(y, scale, shift, w, bias, dpool, B, H, W, C, pool, drop_p, rng_stre
     part_db = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
     part_st = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
     flops = 3 * 2.0 * B * H * W * C * C
-    _launch((f"glu_bwd3_kernel<{C}>", 1, C, C, H, W), flops,
+    _launch((f"glu_bwd3_kernel<{C}, {4 if TW == 16 else -1}>", 1, C, C, H, W), flops,
             lambda: L.call("bsed_glu_bwd3", L.ptr(y), L.ptr(scale), L.ptr(shift), _fp(_dp(w)), _fp(_dp(bias)),
                            L.ptr(dpool), L.ptr(g), L.ptr(part_dw), L.ptr(part_db), L.ptr(part_st), _i(G), _i(B), _i(H),
                            _i(W), _i(C), _i(TH), _i(TW), _i(ph), _i(pw), ctypes.c_float(drop_p),

@@ -249,7 +249,8 @@ int bsed_glu16_bwd(const float* y, const float* scale, const float* shift, const
  *   bwd   : x, dpool -> per-workgroup partials part_dw (G,16,16), part_db (G,2,16) [slot 0], part_st (G,2,16) =
  *           (sum g, sum g*y) for bsed_bn_bwd (coefficients only), part_gx (G,9,16)
  *   wgrad_finish : dst (16,1,3,3) (+)= A Gx + B (Yx - mean Sx) + C Sx with coef = [A|B|C] of bsed_bn_bwd */
-int bsed_block0_stats(const float* x, const float* cw, const float* cb, float* stats, float* xr_part, double* xr64,
+int bsed_block0_stats(const float* x, const float* cw_t /* the (16,1,3,3) weight transposed: [tap][channel] */,
+                      const float* cb, float* stats, float* xr_part, double* xr64,
                       int G, int NB, int H, int W, int CO, void* stream);
 int bsed_block0_fwd(const float* x, const float* cw, const float* cb, const float* scale, const float* shift,
                     const float* wg, const float* bg, float* out, int B, int H, int W, int CO, int ph, int pw,

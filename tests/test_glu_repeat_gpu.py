@@ -1,0 +1,36 @@
+"""Bitwise repeatability of every split-fp32 GLU kernel instance at the shapes of the B = 256 train step (forward,
+fused backward C = 32 / 64, backward C = 128 with its d_lin output): the same inputs give the same bits, whatever
+the allocator hands out in between.  A scheduling-dependent hazard (a compile-time-tile-width build of the C = 128
+backward changed whole elements of g / d_lin between runs while meeting every tolerance-based bar) is invisible to
+parity tests; this one sees it.  Reference: src/models/CNN.py:5-16,59-67 (GLU / Dropout / AvgPool2d) and its autograd."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = ((32, 432, 64, (2, 2)), (64, 216, 32, (1, 2)), (128, 216, 16, (1, 2)), (128, 216, 8, (1, 2)),
+          (128, 216, 4, (1, 2)), (128, 216, 2, (1, 2)))
+
+
+@pytest.mark.parametrize("C,H,W,pool", SHAPES)
+def test_glu_kernels_are_bitwise_repeatable(C, H, W, pool):
+    from bsed_amd import ops
+    B = 64
+    g = torch.Generator(device="cuda").manual_seed(3)
+    y = torch.randn(B, H, W, C, device="cuda", generator=g)
+    sc = torch.rand(C, device="cuda", generator=g) + 0.5
+    sh = torch.randn(C, device="cuda", generator=g) * 0.1
+    w = torch.randn(C, C, device="cuda", generator=g) * 0.1
+    b = torch.randn(C, device="cuda", generator=g) * 0.1
+    dp = torch.randn(B, H // pool[0], W // pool[1], C, device="cuda", generator=g) * 1e-3
+    outs = []
+    for rep in range(3):
+        junk = torch.empty((rep + 1) << 20, device="cuda")   # shift the allocator between repetitions
+        f = ops.glu_fwd3(y, sc, sh, w, b, B, H, W, C, pool, 0.5, 101, 7)
+        r = (ops.glu_bwd3n if C == 128 else ops.glu_bwd3)(y, sc, sh, w, b, dp, B, H, W, C, pool, 0.5, 101, 7)
+        torch.cuda.synchronize()
+        outs.append([f.clone()] + [t.clone() for t in r if torch.is_tensor(t)])
+        del junk
+    for rep in (1, 2):
+        bad = [i for i, (a, c) in enumerate(zip(outs[0], outs[rep])) if not torch.equal(a, c)]
+        assert not bad, (rep, bad)
