@@ -240,6 +240,10 @@ class Clip_Discriminator(_FlatModule):
     def run_backward(self, ctx, grl_coeff):
         """Accumulates the discriminator's parameter gradients; returns dL/d feat (N,T,256) already multiplied by
         -grl_coeff (the gradient-reverse layer)."""
+        with ops.deferred_reductions():   # the weight / bias gradient reductions go out in one launch at the end
+            return self._run_backward(ctx, grl_coeff)
+
+    def _run_backward(self, ctx, grl_coeff):
         N = ctx["N"]
         lay = ctx["layers"]
         dense = self.P("dense_d")
@@ -263,7 +267,7 @@ class Clip_Discriminator(_FlatModule):
                 dy[:, :, l["Wo"]:, :] = 0
                 part, G, KP, NP = ops.wgrad(l["xp"], dy, N, Hp, Wp, K, co, taps=TAPS2x2)
                 tmp = torch.empty((4, K, co), device=dy.device, dtype=torch.float32)
-                ops.reduce_partials(part, G, 4, KP, NP, K, co, tmp, K * co, co, 1, accumulate=False)
+                ops.reduce_partials(part, G, 4, KP, NP, K, co, tmp, K * co, co, 1, accumulate=False, defer=False)
                 w.grad.add_(tmp.view(16, cin, co)[_S2D_SLOT].permute(2, 1, 0).reshape(co, cin, 3, 3))
                 flipped = [(-a, -b) for a, b in TAPS2x2]
                 if self.conv_mode == "bf16x3":

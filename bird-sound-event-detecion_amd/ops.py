@@ -390,8 +390,9 @@ def flush_reductions():
         pending = rest
 
 
-def reduce_partials(part, G, ntaps, KP, NP, K, N, dst, s_tap, s_k, s_n, accumulate=True, dst_offset=0):
-    if _rq is not None and _rq["stream"] == L.stream().value:
+def reduce_partials(part, G, ntaps, KP, NP, K, N, dst, s_tap, s_k, s_n, accumulate=True, dst_offset=0, defer=True):
+    """defer=False: run now even inside ops.deferred_reductions() (the caller reads dst right away)"""
+    if defer and _rq is not None and _rq["stream"] == L.stream().value:
         _rq["jobs"].append((part, _dp(dst, dst_offset), G, ntaps, KP, NP, K, N, s_tap, s_k, s_n, 1 if accumulate else 0))
         return
     _note("reduce_partials_kernel", f"G{G}", float(part.numel()), 4.0 * part.numel())
