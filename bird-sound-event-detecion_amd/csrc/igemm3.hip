@@ -501,7 +501,11 @@ extern "C" int bsed_igemm3(const BsedIgemmDesc* desc, void* stream) {
     BSED_CHECK_ARG(abs(d.dh[t]) <= d.hh && abs(d.dw[t]) <= d.hw, "bsed_igemm3: tap %d outside the halo", t);
   BSED_CHECK_ARG(d.in_pitch >= d.CIN && d.in_pitch % 4 == 0 && d.out_pitch >= d.N, "bsed_igemm3: bad pitch");
   BSED_CHECK_ARG(d.NP % 32 == 0 && d.NP >= d.N, "bsed_igemm3: NP must be N rounded up to 32");
-  const int BN = d.NP % 128 == 0 ? 128 : (d.NP % 64 == 0 ? 64 : 32);
+  int BN = d.NP % 128 == 0 ? 128 : (d.NP % 64 == 0 ? 64 : 32);
+  {  // A/B knob: BSED_IGEMM3_BN=64 runs the 128-channel layers as two 64-channel workgroups per tile
+    static const int bn_cap = getenv("BSED_IGEMM3_BN") ? atoi(getenv("BSED_IGEMM3_BN")) : 128;
+    if (RB == 1 && BN > bn_cap && (bn_cap == 64 || bn_cap == 32)) BN = bn_cap;
+  }
   BSED_CHECK_ARG(RB == 1 || BN == 128, "bsed_igemm3: 256-position tiles are built for N a multiple of 128");
   d.tilesH = ceil_div(d.H, d.TH);
   d.tilesW = d.W / d.TW;

@@ -253,6 +253,9 @@ def igemm3(inp, w3, N, NB, H, W, CIN, taps, bias=None, epilogue=EPI_PLAIN, valid
     TH, TW = tile_for(W)
     NP = w3.shape[2]
     bn = 128 if NP % 128 == 0 else (64 if NP % 64 == 0 else 32)
+    import os
+    if os.environ.get("BSED_IGEMM3_BN") in ("64", "32"):   # A/B knob (csrc/igemm3.hip): labels follow the launch
+        bn = min(bn, int(os.environ["BSED_IGEMM3_BN"]))
     # 256-position tiles (two row blocks per wave: half the LDS reads and weight-slab stagings per MFMA) when they
     # still fill the chip: 128 output channels per workgroup and at least ~4 workgroups per CU
     rb = 2 if (IGEMM3_RB["rb"] == 2 and bn == 128 and H >= 2 * TH and (2 * TH + 2) * (TW + 2) <= 384 and
