@@ -226,13 +226,19 @@ struct B0Win {
     }
   }
   // issue the loads of the window whose first row / column are (r0 - 1, c0 - 1) in image b
+  // (NB * H * W < 2^31, checked on the host; SMALL: the tensor is below 4 GB, so the address is the uniform base plus
+  //  a 32-bit BYTE offset -- one VALU instruction instead of a 64-bit multiply-add chain per load)
+  template <bool SMALL>
   __device__ __forceinline__ void fetch(const float* __restrict__ x, int b, int r0, int c0, int H, int W) {
-    const int base = b * H;   // NB * H * W < 2^31 (checked on the host): 32-bit element offsets
+    const int base = b * H;
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
       const int r = r0 - 1 + ej[k], c = c0 - 1 + ec[k];
       const bool ok = r >= 0 && r < H && c >= 0 && c < W;
-      const float t = x[(base + min(max(r, 0), H - 1)) * W + min(max(c, 0), W - 1)];
+      const int idx = (base + min(max(r, 0), H - 1)) * W + min(max(c, 0), W - 1);
+      float t;
+      if (SMALL) t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + ((uint32_t)idx << 2));
+      else t = x[idx];
       v[k] = ok ? t : 0.f;
     }
   }
@@ -275,7 +281,7 @@ struct B0Conv {
 // forward: x -> conv -> BN-apply -> Linear -> gate -> dropout -> PH x pw average pool -> pooled
 // ---------------------------------------------------------------------------------------------
 #define B0F_THREADS 512
-template <int PH>
+template <int PH, bool SMALL>
 __global__ __launch_bounds__(B0F_THREADS) void b0_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ cw, const float* __restrict__ cb,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ wg,
@@ -303,13 +309,13 @@ __global__ __launch_bounds__(B0F_THREADS) void b0_fwd_kernel(
   cur.init(blockIdx.x, gridDim.x, Hp, chunks);
   B0Win<PH> X;
   X.init(lane);
-  X.fetch(x, cur.b < B ? cur.b : 0, cur.hp * PH, cur.ch * (B0F_THREADS / 4) + wave * 16, H, W);
+  X.template fetch<SMALL>(x, cur.b < B ? cur.b : 0, cur.hp * PH, cur.ch * (B0F_THREADS / 4) + wave * 16, H, W);
   for (; cur.b < B; cur = nxt) {
     X.store(win, lane);
     nxt = cur.next();
     {
       const B0Idx& I = nxt.b < B ? nxt : cur;   // the last prefetch re-reads the current item: no branch
-      X.fetch(x, I.b, I.hp * PH, I.ch * (B0F_THREADS / 4) + wave * 16, H, W);
+      X.template fetch<SMALL>(x, I.b, I.hp * PH, I.ch * (B0F_THREADS / 4) + wave * 16, H, W);
     }
     const int hp = cur.hp, b = cur.b;
     const int w = cur.ch * (B0F_THREADS / 4) + col;
@@ -320,14 +326,20 @@ __global__ __launch_bounds__(B0F_THREADS) void b0_fwd_kernel(
     for (int dh = 0; dh < PH; ++dh) {
       const int h = hp * PH + dh;
       const size_t pos = ((size_t)b * H + h) * W + wc;
+      const uint32_t pos32 = (uint32_t)((b * H + h) * W + wc);
       const f32x4 y = K.run(win, dh);
       float xn[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) xn[i] = fmaf(y[i], sc[i], sh[i]);
       const f32x4 lin = b0_mm16(a1, xn[0], xn[1], xn[2], xn[3], f32x4{0.f, 0.f, 0.f, 0.f});
       float dm[4];
-      drop_mul2((uint64_t)pos * C + 4 * q, dkey, dthr, dscale, dm[0], dm[1]);
-      drop_mul2((uint64_t)pos * C + 4 * q + 2, dkey, dthr, dscale, dm[2], dm[3]);
+      if (SMALL) {   // fewer than 2^32 elements: 32-bit counters (same masks)
+        drop_mul2_32(pos32 * C + 4 * q, dkey, dthr, dscale, dm[0], dm[1]);
+        drop_mul2_32(pos32 * C + 4 * q + 2, dkey, dthr, dscale, dm[2], dm[3]);
+      } else {
+        drop_mul2((uint64_t)pos * C + 4 * q, dkey, dthr, dscale, dm[0], dm[1]);
+        drop_mul2((uint64_t)pos * C + 4 * q + 2, dkey, dthr, dscale, dm[2], dm[3]);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) pooled[i] += (lin[i] + bi[i]) * sigmoid_fast(xn[i]) * dm[i];
     }
@@ -337,7 +349,12 @@ __global__ __launch_bounds__(B0F_THREADS) void b0_fwd_kernel(
     }
     if (ok && (w & (pw - 1)) == 0 && (w >> (pw >> 1)) < Wp) {   // pw is 1 or 2
       const float4 o = make_float4(pooled[0] * inv, pooled[1] * inv, pooled[2] * inv, pooled[3] * inv);
-      *reinterpret_cast<float4*>(out + (((size_t)b * Hp + hp) * Wp + (w >> (pw >> 1))) * C + 4 * q) = o;
+      if (SMALL) {
+        const uint32_t ob = (uint32_t)((((b * Hp + hp) * Wp + (w >> (pw >> 1))) * C + 4 * q) << 2);
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + ob) = o;
+      } else {
+        *reinterpret_cast<float4*>(out + (((size_t)b * Hp + hp) * Wp + (w >> (pw >> 1))) * C + 4 * q) = o;
+      }
     }
   }
 }
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(B0F_THREADS) void b0_fwd_kernel(
 #define B0B_THREADS 256
 #define B0_TP 20   // pitch of the transpose tiles (floats)
 
-template <int PH>
+template <int PH, bool SMALL>
 __global__ __launch_bounds__(B0B_THREADS, 3) void b0_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ cw, const float* __restrict__ cb,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ wg,
@@ -403,10 +420,15 @@ __global__ __launch_bounds__(B0B_THREADS, 3) void b0_bwd_kernel(
   X.init(lane);
   float4 nd = make_float4(0.f, 0.f, 0.f, 0.f);
   auto fetch = [&](const B0Idx& I) {
-    X.fetch(x, I.b, I.hp * PH, I.ch * (B0B_THREADS / 4) + wave * 16, H, W);
+    X.template fetch<SMALL>(x, I.b, I.hp * PH, I.ch * (B0B_THREADS / 4) + wave * 16, H, W);
     const int w = min(I.ch * (B0B_THREADS / 4) + col, W - 1);
     const int wpi = min(w >> spw, Wp - 1);
-    nd = *reinterpret_cast<const float4*>(dpool + (((size_t)I.b * Hp + I.hp) * Wp + wpi) * C + 4 * q);
+    if (SMALL) {
+      const uint32_t ob = (uint32_t)((((I.b * Hp + I.hp) * Wp + wpi) * C + 4 * q) << 2);
+      nd = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dpool) + ob);
+    } else {
+      nd = *reinterpret_cast<const float4*>(dpool + (((size_t)I.b * Hp + I.hp) * Wp + wpi) * C + 4 * q);
+    }
   };
   if (cur.b < B) fetch(cur);
   for (; cur.b < B; cur = nxt) {
@@ -423,6 +445,7 @@ __global__ __launch_bounds__(B0B_THREADS, 3) void b0_bwd_kernel(
     for (int dh = 0; dh < PH; ++dh) {
       const int h = hp * PH + dh;
       const size_t pos = ((size_t)b * H + h) * W + min(w, W - 1);
+      const uint32_t pos32 = (uint32_t)((b * H + h) * W + min(w, W - 1));
       const f32x4 yv = K.run(win, dh);
       float xn[4];
 #pragma unroll
@@ -430,8 +453,13 @@ __global__ __launch_bounds__(B0B_THREADS, 3) void b0_bwd_kernel(
       const f32x4 lin = b0_mm16(a1, xn[0], xn[1], xn[2], xn[3], f32x4{0.f, 0.f, 0.f, 0.f});
       float dl[4], dm[4];
       f32x4 gt;
-      drop_mul2((uint64_t)pos * C + 4 * q, dkey, dthr, dscale, dm[0], dm[1]);
-      drop_mul2((uint64_t)pos * C + 4 * q + 2, dkey, dthr, dscale, dm[2], dm[3]);
+      if (SMALL) {
+        drop_mul2_32(pos32 * C + 4 * q, dkey, dthr, dscale, dm[0], dm[1]);
+        drop_mul2_32(pos32 * C + 4 * q + 2, dkey, dthr, dscale, dm[2], dm[3]);
+      } else {
+        drop_mul2((uint64_t)pos * C + 4 * q, dkey, dthr, dscale, dm[0], dm[1]);
+        drop_mul2((uint64_t)pos * C + 4 * q + 2, dkey, dthr, dscale, dm[2], dm[3]);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float sg = sigmoid_fast(xn[i]);
@@ -579,12 +607,14 @@ extern "C" int bsed_block0_fwd(const float* x, const float* cw, const float* cb,
   const long items = (long)B * (H / ph) * ((W + B0F_THREADS / 4 - 1) / (B0F_THREADS / 4));
   const dim3 grid((unsigned)std::min<long>(items, 8192));
   hipStream_t s = (hipStream_t)stream;
-  if (ph == 2)
-    hipLaunchKernelGGL(b0_fwd_kernel<2>, grid, dim3(B0F_THREADS), 0, s, x, cw, cb, scale, shift, wg, bg, out, B, H, W, pw,
-                       drop_p, rng_stream, seed);
-  else
-    hipLaunchKernelGGL(b0_fwd_kernel<1>, grid, dim3(B0F_THREADS), 0, s, x, cw, cb, scale, shift, wg, bg, out, B, H, W, pw,
-                       drop_p, rng_stream, seed);
+  // SMALL: fewer than 2^28 positions (every tensor below 4 GB, element counters below 2^32): 32-bit offsets
+  const bool small = (long)B * H * W < (1L << 28);
+#define B0_LAUNCH_FWD(PH_, SM_)                                                                                      \
+  hipLaunchKernelGGL((b0_fwd_kernel<PH_, SM_>), grid, dim3(B0F_THREADS), 0, s, x, cw, cb, scale, shift, wg, bg, out, B, \
+                     H, W, pw, drop_p, rng_stream, seed)
+  if (ph == 2) { if (small) B0_LAUNCH_FWD(2, true); else B0_LAUNCH_FWD(2, false); }
+  else { if (small) B0_LAUNCH_FWD(1, true); else B0_LAUNCH_FWD(1, false); }
+#undef B0_LAUNCH_FWD
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }
@@ -600,12 +630,13 @@ extern "C" int bsed_block0_bwd(const float* x, const float* cw, const float* cb,
                      H >= ph, "bsed_block0_bwd: bad shape");
   BSED_CHECK_ARG((long)B * H * W < (1L << 31), "bsed_block0_bwd: too many positions");
   hipStream_t s = (hipStream_t)stream;
-  if (ph == 2)
-    hipLaunchKernelGGL(b0_bwd_kernel<2>, dim3(G), dim3(B0B_THREADS), 0, s, x, cw, cb, scale, shift, wg, bg, dpool,
-                       part_dw, part_db, part_st, part_gx, B, H, W, pw, drop_p, rng_stream, seed);
-  else
-    hipLaunchKernelGGL(b0_bwd_kernel<1>, dim3(G), dim3(B0B_THREADS), 0, s, x, cw, cb, scale, shift, wg, bg, dpool,
-                       part_dw, part_db, part_st, part_gx, B, H, W, pw, drop_p, rng_stream, seed);
+  const bool small = (long)B * H * W < (1L << 28);
+#define B0_LAUNCH_BWD(PH_, SM_)                                                                                       \
+  hipLaunchKernelGGL((b0_bwd_kernel<PH_, SM_>), dim3(G), dim3(B0B_THREADS), 0, s, x, cw, cb, scale, shift, wg, bg, dpool, \
+                     part_dw, part_db, part_st, part_gx, B, H, W, pw, drop_p, rng_stream, seed)
+  if (ph == 2) { if (small) B0_LAUNCH_BWD(2, true); else B0_LAUNCH_BWD(2, false); }
+  else { if (small) B0_LAUNCH_BWD(1, true); else B0_LAUNCH_BWD(1, false); }
+#undef B0_LAUNCH_BWD
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }

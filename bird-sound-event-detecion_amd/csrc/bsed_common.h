@@ -138,6 +138,15 @@ __device__ __forceinline__ void drop_mul2(uint64_t e_even, uint32_t key, uint32_
   m1 = (h >> 16) >= thr16 ? scale : 0.f;
 }
 
+// the same two multipliers for element indices below 2^32 (the (e >> 32) term of drop_mul2 is zero there): 32-bit
+// index arithmetic only
+__device__ __forceinline__ void drop_mul2_32(uint32_t e_even, uint32_t key, uint32_t thr16, float scale, float& m0,
+                                             float& m1) {
+  const uint32_t h = mix32((e_even >> 1) * 0x9E3779B1u + key);
+  m0 = (h & 0xFFFFu) >= thr16 ? scale : 0.f;
+  m1 = (h >> 16) >= thr16 ? scale : 0.f;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -484,7 +484,7 @@ def block0_stats(x, cw, cb, NB, H, W):
 def block0_fwd(x, cw, cb, scale, shift, wg, bg, B, H, W, pool, drop_p, rng_stream, seed):
     ph, pw = pool
     out = torch.empty((B, H // ph, W // pw, 16), device=x.device, dtype=torch.float32)
-    _note(f"b0_fwd_kernel<{ph}>", f"{H}x{W}", 2.0 * B * H * W * (9 * 16 + 256),
+    _note(f"b0_fwd_kernel<{ph}, {'true' if B * H * W < (1 << 28) else 'false'}>", f"{H}x{W}", 2.0 * B * H * W * (9 * 16 + 256),
           4.0 * B * H * W * (1.0 + 16.0 / (ph * pw)))
     L.call("bsed_block0_fwd", L.ptr(x), _fp(_dp(cw)), _fp(_dp(cb)), L.ptr(scale), L.ptr(shift), _fp(_dp(wg)),
            _fp(_dp(bg)), L.ptr(out), _i(B), _i(H), _i(W), _i(16), _i(ph), _i(pw), ctypes.c_float(drop_p),
@@ -501,7 +501,7 @@ def block0_bwd(x, cw, cb, scale, shift, wg, bg, dpool, B, H, W, pool, drop_p, rn
     part_db = torch.empty((G, 2, 16), device=dev, dtype=torch.float32)
     part_st = torch.empty((G, 2, 16), device=dev, dtype=torch.float32)
     part_gx = torch.empty((G, 9, 16), device=dev, dtype=torch.float32)
-    _note(f"b0_bwd_kernel<{ph}>", f"{H}x{W}", 2.0 * B * H * W * (2 * 9 * 16 + 3 * 256),
+    _note(f"b0_bwd_kernel<{ph}, {'true' if B * H * W < (1 << 28) else 'false'}>", f"{H}x{W}", 2.0 * B * H * W * (2 * 9 * 16 + 3 * 256),
           4.0 * B * H * W * (1.0 + 16.0 / (ph * pw)))
     L.call("bsed_block0_bwd", L.ptr(x), _fp(_dp(cw)), _fp(_dp(cb)), L.ptr(scale), L.ptr(shift), _fp(_dp(wg)),
            _fp(_dp(bg)), L.ptr(dpool), L.ptr(part_dw), L.ptr(part_db), L.ptr(part_st), L.ptr(part_gx), _i(G), _i(B),
