@@ -17,6 +17,12 @@
 #define I3_M 128
 #define I3_KC 32
 #define I3_ROW 72  // ushorts per LDS row: 32 hi + 32 lo + 8 pad
+// Ablation builds (diagnostic, tools/build_variant.sh <tag> igemm3.hip "-DI3_ABL=<bits>"; results are WRONG by design):
+//   1 = no MFMAs (fragments kept live), 2 = no fragment reads from LDS (constant fragments), 4 = no epilogue stores,
+//   8 = no weight-slab staging (one slab, no per-tap barriers), 16 = no activation-patch loads after the first chunk
+#ifndef I3_ABL
+#define I3_ABL 0
+#endif
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -117,6 +123,7 @@ void igemm3_kernel(const Igemm3Params P) {
 #pragma unroll
     for (int u = 0; u < NT; ++u) pre[u] = wthr[u * I3_THREADS];
     for (int tap = 0; tap < p.ntaps; ++tap) {
+      if (!(I3_ABL & 8) || tap == 0) {
       if (tap > 0) __syncthreads();  // every wave is done reading the previous slab
 #pragma unroll
       for (int u = 0; u < NT; ++u) {
@@ -124,12 +131,13 @@ void igemm3_kernel(const Igemm3Params P) {
         *reinterpret_cast<u32x4*>(Bs + (e >> 3) * I3_ROW + (e & 7) * 8) = pre[u];
       }
       __syncthreads();
-      if (tap == 0 && ch + 1 < nchunks) {  // next chunk's patch: in flight during this chunk's taps
+      }
+      if (tap == 0 && ch + 1 < nchunks && !(I3_ABL & 16)) {  // next chunk's patch: in flight during this chunk's taps
 #pragma unroll
         for (int u = 0; u < PV; ++u)
           pv[u] = poff[u] >= 0 ? *reinterpret_cast<const f32x4*>(inb + poff[u] + (ch + 1) * I3_KC) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      {  // next tap's slab (the last tap re-reads its own: no branch around the loads)
+      if (!(I3_ABL & 8)) {  // next tap's slab (the last tap re-reads its own: no branch around the loads)
         const u32x4* wn = wthr + (size_t)min(tap + 1, p.ntaps - 1) * tap_stride;
 #pragma unroll
         for (int u = 0; u < NT; ++u) pre[u] = wn[u * I3_THREADS];
@@ -144,16 +152,33 @@ void igemm3_kernel(const Igemm3Params P) {
       for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
+          if (I3_ABL & 2) {
+            a_hi[kk][rb] = bf16x8{(short)toff, 1, 2, 3, 4, 5, 6, (short)tid}; a_lo[kk][rb] = a_hi[kk][rb];
+          } else {
           a_hi[kk][rb] = *reinterpret_cast<const bf16x8*>(As + abase[rb] + toff + 16 * kk);
           a_lo[kk][rb] = *reinterpret_cast<const bf16x8*>(As + abase[rb] + toff + 32 + 16 * kk);
+          }
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
+          if (I3_ABL & 2) {
+            b_hi[kk][j] = bf16x8{(short)tap, 1, 2, 3, 4, 5, 6, (short)(tid + j)}; b_lo[kk][j] = b_hi[kk][j];
+          } else {
           b_hi[kk][j] = *reinterpret_cast<const bf16x8*>(brow + 32 * j * I3_ROW + 16 * kk);
           b_lo[kk][j] = *reinterpret_cast<const bf16x8*>(brow + 32 * j * I3_ROW + 32 + 16 * kk);
+          }
         }
       }
       // independent accumulators are interleaved so that consecutive MFMAs never depend on each other
+      if (I3_ABL & 1) {   // keep the fragments live without multiplying
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) asm volatile("" :: "v"(a_hi[kk][rb]), "v"(a_lo[kk][rb]));
+#pragma unroll
+          for (int j = 0; j < NT; ++j) asm volatile("" :: "v"(b_hi[kk][j]), "v"(b_lo[kk][j]));
+        }
+      } else
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -195,7 +220,7 @@ void igemm3_kernel(const Igemm3Params P) {
       for (int j = 0; j < NT; ++j) {
         if (pok && nok[j]) {
           const float v = acc[rb][j][r] + bias[j];
-          orow[32 * j] = v;
+          if (!(I3_ABL & 4) || v == 123.456f) orow[32 * j] = v;
           if (STATS) { s0[j] += v; s1[j] = fmaf(v, v, s1[j]); }
         }
       }
