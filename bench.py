@@ -176,6 +176,10 @@ def main():
                          "cnn = configs[1] (CNN-only tagging forward, CRNN_pred, batch 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--timer-steps", type=int, default=10,
+                    help="the per-launch HIP events (roofline leg) are recorded during the first N of the timed steps "
+                         "(0 = all of them): each event costs the GPU ~1.5 us, 2-3 %% of a step when every launch of every "
+                         "step carries one")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 64 if args.mode == "cnn" else 256
@@ -309,7 +313,10 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    tsteps = args.steps if args.timer_steps <= 0 else min(args.timer_steps, args.steps)
+    for i in range(args.steps):
+        if timer is not None and i == tsteps:
+            ops.set_timer(None)     # the remaining timed steps run without per-launch events
         out = step()
     torch.cuda.synchronize()
     if world > 1:
@@ -341,7 +348,7 @@ def main():
         for k in sorted(summ, key=lambda k: -summ[k][1]):
             c, tms, ams, fl, nb = summ[k]
             log("  %-58s x%-3d %8.3f ms/step  avg %7.3f ms  %6.1f TFLOP/s %6.0f GB/s" % (
-                "%s %s" % k, c // args.steps, tms / args.steps, ams, fl / ams / 1e9, nb / ams / 1e6))
+                "%s %s" % k, c // tsteps, tms / tsteps, ams, fl / ams / 1e9, nb / ams / 1e6))
         # the roofline object is quoted per KERNEL (template instance, the unit rocprofv3 --stats aggregates on): all its
         # launches of the timed region with their algorithmic FLOPs and bytes; EVERY launch of the step is timed (mel,
         # first block, BatchNorm, GRU, head, optimizer and glue included), so the kernel named is the step's dominant one
@@ -352,11 +359,12 @@ def main():
         for name in sorted(byk, key=lambda n: -byk[n][1]):
             c, tms, fl, nb = byk[name]
             log("  KERNEL %-40s x%-3d %8.3f ms/step  avg %7.3f ms  %6.1f TFLOP/s %6.0f GB/s" % (
-                name, c // args.steps, tms / args.steps, tms / c, fl / tms / 1e9, nb / tms / 1e6))
+                name, c // tsteps, tms / tsteps, tms / c, fl / tms / 1e9, nb / tms / 1e6))
         name = max(byk, key=lambda n: byk[n][1])
         roofline = kernel_roofline(name, *byk[name])
         roofline["share_of_kernel_time"] = round(byk[name][1] / tot_ms, 3)
-        roofline["kernels_ms_per_step"] = round(tot_ms / args.steps, 3)
+        roofline["kernels_ms_per_step"] = round(tot_ms / tsteps, 3)
+        roofline["timed_steps_with_events"] = tsteps
         # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # passes, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for the profiled workload
         try:

@@ -23,6 +23,7 @@
 #include "bsed_common.h"
 #include "../../include/bsed.h"
 #include <algorithm>
+#include <stdlib.h>
 
 #define B0_C 16
 #define B0_NXR 54   // Sx[9] then R packed upper triangle (t <= t'): 45
@@ -605,7 +606,8 @@ extern "C" int bsed_block0_fwd(const float* x, const float* cw, const float* cb,
   BSED_CHECK_ARG(B > 0 && H > 0 && W > 0 && (ph == 1 || ph == 2) && (pw == 1 || pw == 2) && W % pw == 0 && H >= ph &&
                      (long)B * H * W < (1L << 31), "bsed_block0_fwd: bad shape");
   const long items = (long)B * (H / ph) * ((W + B0F_THREADS / 4 - 1) / (B0F_THREADS / 4));
-  const dim3 grid((unsigned)std::min<long>(items, 8192));
+  static const long gmax = getenv("BSED_B0_FWD_G") ? atol(getenv("BSED_B0_FWD_G")) : 8192;   // A/B knob
+  const dim3 grid((unsigned)std::min<long>(items, gmax));
   hipStream_t s = (hipStream_t)stream;
   // SMALL: fewer than 2^28 positions (every tensor below 4 GB, element counters below 2^32): 32-bit offsets
   const bool small = (long)B * H * W < (1L << 28);

@@ -469,7 +469,8 @@ def glu16_bwd(y, scale, shift, wg, bg, dpool, B, H, W, pool, drop_p, rng_stream,
 
 def block0_stats(x, cw, cb, NB, H, W):
     """train-mode statistics of the first block from x alone: returns (stats (G,2,16) for bn_finalize, xr64 (54,) fp64)"""
-    G = int(min(2048, max(1, (NB * H * W) // 256)))
+    import os
+    G = int(min(int(os.environ.get("BSED_B0_STATS_G", "2048")), max(1, (NB * H * W) // 256)))   # (A/B knob)
     dev = x.device
     stats = torch.empty((G, 2, 16), device=dev, dtype=torch.float32)
     xr_part = torch.empty((G, 54), device=dev, dtype=torch.float32)
@@ -496,7 +497,8 @@ def block0_bwd(x, cw, cb, scale, shift, wg, bg, dpool, B, H, W, pool, drop_p, rn
     """returns (part_dw (G,16,16), part_db (G,2,16), part_st (G,2,16), part_gx (G,9,16), G)"""
     ph, pw = pool
     dev = x.device
-    G = int(min(2048, B * (H // ph)))
+    import os
+    G = int(min(int(os.environ.get("BSED_B0_BWD_G", "8192")), B * (H // ph)))   # 2048 / 4096 / 8192 workgroups: 0.983 / 0.966 / 0.957 ms
     part_dw = torch.empty((G, 16, 16), device=dev, dtype=torch.float32)
     part_db = torch.empty((G, 2, 16), device=dev, dtype=torch.float32)
     part_st = torch.empty((G, 2, 16), device=dev, dtype=torch.float32)
