@@ -304,7 +304,7 @@ class CRNN(_FlatModule):
         ph, pw = pool
         cw, cb = self.P(names[0] + ".weight"), self.P(names[0] + ".bias")
         taps, wsrc, s_tap = self._conv_taps(cw, Ww)
-        if first and co == 16 and self.block0_fused and Ww > 1:
+        if first and co == 16 and self.block0_fused and 1 < Ww <= 256 and B * Hh * Ww < (1 << 31):
             return self._block0_forward(a, B, Hh, Ww, pool, names, drop, rng_stream, nbt, train)
         if first:
             y, stats = ops.conv0_fwd(a, cw, cb, B, Hh, Ww, co, want_stats=train)

@@ -83,6 +83,41 @@ def test_fused_block0_equals_the_four_kernel_form(B, T, dropout):
         assert err <= 1e-5 * float(b.norm()) + 1e-9, (name, err, float(b.norm()))
 
 
+def test_fused_block0_kernels_on_other_map_widths():
+    """the block's kernels on maps that are not 128 wide (40: partial 16-column wave tiles; 192: two column chunks in
+    the backward kernel, three waves per row in the statistics kernel) against the four-kernel form, kernel by kernel"""
+    from bsed_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for B, H, W in ((3, 33, 40), (2, 18, 192)):
+        x = torch.rand(B, H, W, device="cuda", generator=g) * 60 - 70
+        cw = torch.randn(16, 1, 3, 3, device="cuda", generator=g) * 0.3
+        cb = torch.randn(16, device="cuda", generator=g) * 0.1
+        wg = torch.randn(16, 16, device="cuda", generator=g) * 0.2
+        bg = torch.randn(16, device="cuda", generator=g) * 0.1
+        y, st = ops.conv0_fwd(x, cw, cb, B, H, W, 16, want_stats=True)
+        st_f, xr64 = ops.block0_stats(x, cw, cb, B, H, W)
+        np.testing.assert_allclose(st_f.double().sum(0).cpu().numpy(), st.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+        # Sx / R against a direct evaluation
+        xp = torch.nn.functional.pad(x.double(), (1, 1, 1, 1))
+        taps = torch.stack([xp[:, kh:kh + H, kw:kw + W] for kh in range(3) for kw in range(3)], 0).reshape(9, -1)
+        want = torch.cat([taps.sum(1), torch.stack([(taps[t] * taps[u]).sum() for t in range(9) for u in range(t, 9)])])
+        np.testing.assert_allclose(xr64.cpu().numpy(), want.cpu().numpy(), rtol=1e-5)
+        scale = torch.rand(16, device="cuda", generator=g) * 0.05 + 0.02
+        shift = torch.randn(16, device="cuda", generator=g) * 0.1
+        for pool in ((2, 2), (1, 2)):
+            a = ops.block0_fwd(x, cw, cb, scale, shift, wg, bg, B, H, W, pool, 0.5, 100, 7)
+            b = ops.glu16_fwd(y, scale, shift, wg, bg, B, H, W, pool, 0.5, 100, 7)
+            assert torch.equal(a, b), (W, pool)
+            dp = torch.randn(tuple(a.shape), device="cuda", generator=g) * 1e-2
+            pdw, pdb, pst, pgx, G = ops.block0_bwd(x, cw, cb, scale, shift, wg, bg, dp, B, H, W, pool, 0.5, 100, 7)
+            gq, qdw, qdb, qst, G2 = ops.glu16_bwd(y, scale, shift, wg, bg, dp, B, H, W, pool, 0.5, 100, 7)
+            for u, v, name in ((pdw, qdw, "dw"), (pdb[:, 0], qdb[:, 0], "db"), (pst, qst, "st")):
+                np.testing.assert_allclose(u.double().sum(0).cpu().numpy(), v.double().sum(0).cpu().numpy(),
+                                           rtol=2e-4, atol=1e-6, err_msg=f"{name} W={W} pool={pool}")
+            gx = torch.einsum("bhwc,tbhw->tc", gq.double(), taps.view(9, B, H, W))     # sum g x_tap, (9, 16)
+            np.testing.assert_allclose(pgx.double().sum(0).cpu().numpy(), gx.cpu().numpy(), rtol=2e-4, atol=1e-6)
+
+
 def test_fused_block0_eval_mode_is_bit_identical():
     seed, B, T = 8, 2, 64
     x = torch.from_numpy(seeded.db_like_input(seed, B, T)).cuda()
