@@ -370,10 +370,13 @@ __global__ __launch_bounds__(B0F_THREADS) void b0_fwd_kernel(
 // accumulator per lane instead of 64 VALU accumulators and 12 cross-lane shuffles per position.
 // ---------------------------------------------------------------------------------------------
 #define B0B_THREADS 256
+#ifndef B0B_WPE
+#define B0B_WPE 3
+#endif
 #define B0_TP 20   // pitch of the transpose tiles (floats)
 
 template <int PH, bool SMALL>
-__global__ __launch_bounds__(B0B_THREADS, 3) void b0_bwd_kernel(
+__global__ __launch_bounds__(B0B_THREADS, B0B_WPE) void b0_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ cw, const float* __restrict__ cb,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ wg,
     const float* __restrict__ bg, const float* __restrict__ dpool, float* __restrict__ part_dw,

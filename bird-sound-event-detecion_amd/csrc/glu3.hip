@@ -150,8 +150,11 @@ __device__ __forceinline__ float drop_mul32(uint32_t e, uint32_t key, uint32_t t
   return (h >> 8) >= thr ? scale : 0.f;
 }
 
+#ifndef G3_B32_WPE
+#define G3_B32_WPE 3
+#endif
 template <int C, int LGTW>
-__global__ __launch_bounds__(G3_THREADS, C == 32 ? 3 : 2) void glu_bwd3_kernel(const Glu3Params P) {
+__global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3_kernel(const Glu3Params P) {
   constexpr int NT = C / 32, KS = C / 16;
   // LGTW >= 0: the tile width is a compile-time constant (16 for every block of the reference network with more than
   // 8 frequency bins), so the per-row index arithmetic of the epilogues -- (m >> lgTW, m & (TW - 1)) of 16 rows per

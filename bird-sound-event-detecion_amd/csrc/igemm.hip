@@ -469,8 +469,14 @@ __device__ __forceinline__ void w3_store4(w3_lds_u16* hi_plane, w3_lds_u16* lo_p
   *(w3_lds_u2*)(lo_plane + o) = lo;
 }
 
+#ifndef W3_SMALL_WPE
+#define W3_SMALL_WPE 4
+#endif
+// the 1- and 2-slot 4-wave forms (conv1 16 -> 32 channels: 39 KB of LDS) are pinned to 128 registers so that FOUR
+// workgroups share a CU: 0.753 (three, 136 registers) -> 0.651 ms, 4.9 TB/s (A/B: -DW3_SMALL_WPE=2)
+#define W3_WPE(MAXS, NW) ((MAXS) <= 2 && (NW) == 4 ? W3_SMALL_WPE : 2)
 template <int MAXS, int NW, bool BS>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) void wgrad3_kernel(const WgradParams P) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(W3_WPE(MAXS, NW)))) void wgrad3_kernel(const WgradParams P) {
   constexpr int NTHR = NW * 64;
   const BsedWgradDesc& p = P.d;
   extern __shared__ __align__(16) uint32_t smw[];
@@ -1597,8 +1603,9 @@ extern "C" int bsed_wgrad3_auto_g(const BsedWgradDesc* desc) {
   if (wgrad_prepare(desc, P, smem, gyz, 1) != BSED_OK) return -1;
   long slots = wgrad3_pipelined(P, smem) ? 256 : smem <= 80 * 1024 ? 512 : 256;
   // small tiles (conv1 16 -> 32 channel gradient: 39 KB, 136 registers): a third workgroup per CU fits and hides more of
-  // the stage / barrier / MFMA serialisation: 0.956 -> 0.753 ms (four per CU: 0.913; BSED_WGRAD3_SLOTS_SMALL for A/B runs)
-  static const int small_slots = getenv("BSED_WGRAD3_SLOTS_SMALL") ? atoi(getenv("BSED_WGRAD3_SLOTS_SMALL")) : 768;
+  // the stage / barrier / MFMA serialisation: 0.956 -> 0.753 ms; a fourth (the kernel pinned to 128 registers) 0.651 ms
+  // (BSED_WGRAD3_SLOTS_SMALL for A/B runs)
+  static const int small_slots = getenv("BSED_WGRAD3_SLOTS_SMALL") ? atoi(getenv("BSED_WGRAD3_SLOTS_SMALL")) : 1024;
   if (!wgrad3_pipelined(P, smem) && smem <= 52 * 1024 && wgrad_variant(P) / 16 <= 2) slots = small_slots;
   long want = std::max<long>(1, slots / ((long)gyz.y * gyz.z));
   // XCD affinity: workgroup (x, y, z) has linear id x + G * (y + gy * z) and lands on XCD id % 8.  The gy * gz

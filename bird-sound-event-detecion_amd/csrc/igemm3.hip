@@ -50,7 +50,13 @@ template <int BN, int STATS, int RB, int PV>
 // kernel fits 152 without a spill; with 38 % of a workgroup's life outside its MFMA loop -- in-kernel stamps -- the
 // third resident workgroup is worth 7 %, so there the minimum is pinned to 3 as well)
 __global__ __launch_bounds__(I3_THREADS)
-__attribute__((amdgpu_waves_per_eu(RB == 2 ? 1 : ((BN == 128 && PV <= 9) ? 3 : 1), RB == 2 ? 2 : 3)))  // (PV = 12 would spill at 3)
+// (BN <= 64: pinned to FOUR waves per SIMD, i.e. 128 registers and a fourth resident workgroup: 0.446 / 0.335 / 0.312 ms ->
+//  0.41 / 0.295 / 0.271 on the 64- and 32-channel layers; A/B: -DI3_WPE_SMALL=3)
+#ifndef I3_WPE_SMALL
+#define I3_WPE_SMALL 4
+#endif
+__attribute__((amdgpu_waves_per_eu(RB == 2 ? 1 : ((BN == 128 && PV <= 9) ? 3 : (BN <= 64 && I3_WPE_SMALL > 3 ? I3_WPE_SMALL : 1)),
+                                   RB == 2 ? 2 : (BN <= 64 ? I3_WPE_SMALL : 3))))  // (PV = 12 would spill at 3)
 void igemm3_kernel(const Igemm3Params P) {
   constexpr int NT = BN / 32;
   const BsedIgemmDesc& p = P.d;
