@@ -347,7 +347,9 @@ __global__ void pack_weight3s_kernel(const float* __restrict__ src, unsigned sho
 // NV = output channels a workgroup really has (32, or 16 for N <= 16): with 16 the plain epilogue would store 64-byte
 // pieces from half the lanes, 16 instructions per tile; instead the tile goes through a wave-private LDS image and
 // leaves as float4 rows, 1 KB of consecutive addresses per instruction (0.59 -> 0.45 ms on the 32 -> 16 channel dgrad).
-#define I3S_EROW 20  // floats per position row of that image: 16 + 4 pad (80 B: 16-byte aligned, odd x 16 B)
+#define I3S_EROW 16  // floats per position row of that image (no pad: the two rows a store instruction touches are 4 rows
+                     // apart = the same banks, a 2-way conflict that a 4-byte store absorbs; 8 KB instead of 10 per workgroup,
+                     // which -- with the half-width weight table below -- lets a THIRD workgroup share the CU's LDS)
 
 template <int STATS, int NTAPS, int KS, int NV>
 __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params P) {
@@ -357,14 +359,21 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
   constexpr int PV = KS == 1 ? 4 : 6;    // float4 patch elements per thread: 256 x 4 / 192 x 8 patch elements
   const BsedIgemmDesc& p = P.d;
   extern __shared__ __align__(16) unsigned short smem3[];
-  u32x4* Wf = reinterpret_cast<u32x4*>(smem3);               // [NTAPS][KS][2][64]
-  unsigned short* As = smem3 + NTAPS * KS * 2 * 64 * 8;      // [PP][I3S_ROW]
+  // NV == 16: output channels 16..31 of the 32-wide MFMA tile do not exist, their weight fragments are never stored:
+  // the table keeps the 32 lanes (li < 16, lh) of every fragment and lanes li >= 16 read the fragment of li - 16
+  constexpr int WL = NV == 16 ? 32 : 64;
+  u32x4* Wf = reinterpret_cast<u32x4*>(smem3);               // [NTAPS][KS][2][WL]
+  unsigned short* As = smem3 + NTAPS * KS * 2 * WL * 8;      // [PP][I3S_ROW]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   float* Es = reinterpret_cast<float*>(As + P.PP * I3S_ROW) + wave * 32 * I3S_EROW;  // NV == 16 only
   const int jn = blockIdx.y, n0 = 32 * jn;
   const int PW = P.PW;
-  for (int i = tid; i < NTAPS * KS * 2 * 64; i += I3_THREADS)
-    Wf[i] = reinterpret_cast<const u32x4*>(p.w)[(size_t)jn * NTAPS * KS * 2 * 64 + i];
+  for (int i = tid; i < NTAPS * KS * 2 * WL; i += I3_THREADS) {
+    const int fr = i / WL, l = i % WL;
+    const int src = NV == 16 ? (l & 15) + 32 * (l >> 4) : l;
+    Wf[i] = reinterpret_cast<const u32x4*>(p.w)[(size_t)jn * NTAPS * KS * 2 * 64 + fr * 64 + src];
+  }
+  const int wlane = NV == 16 ? (li & 15) + 16 * lh : lane;
   const int m = wave * 32 + li;
   const int abase = (((m >> P.lgTW) + p.hh) * PW + (m & (p.TW - 1)) + p.hw) * I3S_ROW + 8 * lh;
   int toff[NTAPS];
@@ -434,8 +443,8 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
       }
 #pragma unroll
       for (int t = 0; t < NTAPS; ++t) {
-        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, Wf[((t * KS + kk) * 2 + 0) * 64 + lane]);
-        const bf16x8 b_lo = __builtin_bit_cast(bf16x8, Wf[((t * KS + kk) * 2 + 1) * 64 + lane]);
+        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, Wf[((t * KS + kk) * 2 + 0) * WL + wlane]);
+        const bf16x8 b_lo = __builtin_bit_cast(bf16x8, Wf[((t * KS + kk) * 2 + 1) * WL + wlane]);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[t], b_hi, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[t], b_lo, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[t], b_hi, acc, 0, 0, 0);
@@ -578,6 +587,13 @@ extern "C" int bsed_igemm3s_auto_g(void) {
   const char* v = getenv("BSED_IGEMM3S_G");   // A/B knob
   return v && atoi(v) > 0 ? atoi(v) : 1024;
 }
+// per shape: the 32 -> 16 channel data gradient (half-width weight table, 52 KB of LDS) runs three workgroups per CU:
+// 768 / 1024 / 1536 workgroups 0.380 / 0.452 / 0.384 ms; the 16 -> 32 forward four: 0.406 / 0.365 / 0.409
+extern "C" int bsed_igemm3s_auto_g2(int CIN, int N) {
+  const char* v = getenv("BSED_IGEMM3S_G");
+  if (v && atoi(v) > 0) return atoi(v);
+  return (CIN == 32 && N <= 16) ? 768 : 1024;
+}
 
 extern "C" int bsed_igemm3s(const BsedIgemmDesc* desc, int G, void* stream) {
   BSED_CHECK_ARG(desc, "bsed_igemm3s: null descriptor");
@@ -614,7 +630,7 @@ extern "C" int bsed_igemm3s(const BsedIgemmDesc* desc, int G, void* stream) {
   BSED_CHECK_ARG(ntiles < (1L << 31) && G > 0 && G <= ntiles, "bsed_igemm3s: G must be in 1..%ld tiles", ntiles);
   // N <= 16: transposed epilogue (wave-private LDS image, float4 row stores)
   const bool nv16 = d.N <= 16 && d.N % 4 == 0 && d.out_pitch % 4 == 0;
-  const size_t bytes = (size_t)d.ntaps * KS * 2 * 64 * 16 + (size_t)P.PP * (2 * d.CIN + 8) * 2 +
+  const size_t bytes = (size_t)d.ntaps * KS * 2 * (nv16 ? 32 : 64) * 16 + (size_t)P.PP * (2 * d.CIN + 8) * 2 +
                        (nv16 ? (size_t)4 * 32 * I3S_EROW * sizeof(float) : 0);
   dim3 grid((unsigned)G, d.NP / 32);
   hipStream_t s = (hipStream_t)stream;

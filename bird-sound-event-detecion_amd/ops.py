@@ -227,7 +227,7 @@ def igemm3s(inp, wtab, N, NB, H, W, taps, bias=None, epilogue=EPI_PLAIN):
     dev = inp.device
     out = torch.empty((NB, H, W, N), device=dev, dtype=torch.float32)
     ntiles = NB * ((H + TH - 1) // TH) * (W // TW)
-    G = int(min(ntiles, L.lib().bsed_igemm3s_auto_g()))
+    G = int(min(ntiles, L.lib().bsed_igemm3s_auto_g2(_i(inp.shape[-1]), _i(N))))
     stats = torch.empty((G, 2, N), device=dev, dtype=torch.float32) if epilogue == EPI_STATS else None
     d.in_ = _dp(inp); d.w = wtab.data_ptr(); d.bias = _p(bias); d.out = _p(out); d.stats = _p(stats)
     CIN = 16 * wtab.shape[2]

@@ -129,6 +129,7 @@ int bsed_pack_weight3s(const float* src, void* dst, int ntaps, int K, int N, int
                        void* stream);
 int bsed_igemm3s(const BsedIgemmDesc* desc, int G, void* stream);
 int bsed_igemm3s_auto_g(void);
+int bsed_igemm3s_auto_g2(int CIN, int N);   /* per shape (resident workgroups differ with the LDS footprint) */
 
 /* dW[tap][k][n] = sum_p in[p + (dh,dw)(tap)][k] * dy[p][n]: persistent workgroups over position tiles
  * write partial slabs part[G][ntaps][CINP][NP]; bsed_reduce_partials sums them into the gradient. */
