@@ -380,8 +380,8 @@ def main():
                         break
         except (OSError, KeyError, ValueError):
             pass
-        # the MFMA-bound kernel with the largest total, for continuity with round 1's line
-        mf = [nm for nm in byk if MFMA_KERNEL.search(nm) and
+        # the bf16-MFMA-bound (split-fp32) kernel with the largest total, for continuity with round 1's line
+        mf = [nm for nm in byk if MFMA_KERNEL.search(nm) and SPLIT_KERNEL.search(nm) and
               byk[nm][2] / max(byk[nm][3], 1.0) >= (PEAK_BF16_MFMA_TFLOPS / 3 if SPLIT_KERNEL.search(nm) else
                                                     PEAK_FP32_MFMA_TFLOPS) * 1e12 / (PEAK_HBM_GBS * 1e9)]
         if mf:
