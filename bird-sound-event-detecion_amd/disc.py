@@ -99,6 +99,11 @@ class Clip_Discriminator(_FlatModule):
         # oracle at 24 x 216 x 256: 6e-4 with fp32 GEMMs (what any fp32 implementation gets), 8e-3 with split-fp32.
         # Loss and outputs agree to 3e-7 either way; parity of the gradients is why fp32 is the default here.
         self.conv_mode = os.environ.get("BSED_DISC_MODE", "fp32")
+        # The mask sensitivity is a property of the FORWARD contractions only (the masks are functions of the forward
+        # pre-activations): the data-gradient GEMMs of the backward pass contract given operands, where split-fp32 costs
+        # its usual 2^-16 and nothing is amplified.  They therefore run on the bf16 cores by default (the weight
+        # gradients always did): -2 ms per adversarial step at B = 128 + 128.  BSED_DISC_BWD_MODE=fp32 for A/B runs.
+        self.bwd_mode = os.environ.get("BSED_DISC_BWD_MODE", "bf16x3")
         self.nbt = torch.zeros(5, device=device, dtype=torch.int64)
         for k in range(1, 6):
             self.P(f"bn_{k}").register_buffer("num_batches_tracked", self.nbt[k - 1])
@@ -270,7 +275,7 @@ class Clip_Discriminator(_FlatModule):
                 ops.reduce_partials(part, G, 4, KP, NP, K, co, tmp, K * co, co, 1, accumulate=False, defer=False)
                 w.grad.add_(tmp.view(16, cin, co)[_S2D_SLOT].permute(2, 1, 0).reshape(co, cin, 3, 3))
                 flipped = [(-a, -b) for a, b in TAPS2x2]
-                if self.conv_mode == "bf16x3":
+                if self.conv_mode == "bf16x3" or self.bwd_mode == "bf16x3":
                     wd3 = ops.pack_weight3(l["wfull"], 4, co, K, K * co, 1, co)
                     dxp, _ = ops.igemm3(dy, wd3, K, N, Hp, Wp, co, flipped)
                 else:
@@ -290,7 +295,7 @@ class Clip_Discriminator(_FlatModule):
                 dyp = torch.zeros((l["M"], cop), device=dy.device, dtype=torch.float32)
                 dyp[:, :co] = dy
                 dy = dyp
-            if self.conv_mode == "bf16x3" and cop % 32 == 0:
+            if (self.conv_mode == "bf16x3" or self.bwd_mode == "bf16x3") and cop % 32 == 0:
                 w3 = ops.pack_weight3(wT, 1, cop, K, 0, wT.shape[2], 1)
                 dcol, _ = ops.igemm3(dy, w3, K, 1, l["M"], 1, cop, ((0, 0),))
             else:
