@@ -279,49 +279,52 @@ class SEDTrainer:
             self.domain_loss.domain_discriminator.train()
         out = {}
         B, Tp, C = syn_y.shape
-        # ---- student on the synthetic batch: strong + weak BCE
-        crnn.set_seed(step_seed * 4 + 0)
-        enc_s, ctx_s = crnn.run_forward(syn_x, save=True)
-        saved_s = pred.run_forward(enc_s)
-        y_weak_syn = syn_y.max(-2)[0].contiguous()
-        dx, lp = pred.run_backward(enc_s, saved_s, y_strong=syn_y.contiguous(), y_weak=y_weak_syn)
-        out["syn"] = lp
-        dft = None
-        if adv:
-            # domain loss on the SAME encodings (the reference runs a second, numerically identical forward when
-            # dropout is 0 -- SURVEY.md 8d); its feature gradients arrive through the gradient-reverse layer
-            crnn.set_seed(step_seed * 4 + 1)
-            enc_r, ctx_r = crnn.run_forward(real_x, save=True)
-            out["domain"] = self.domain_loss(None, enc_s, None, enc_r)
-            dfs, dft = self.domain_loss.backward_features()
-            ops.axpy(dx, dfs)
-        # the gradient exchange starts inside the LAST backward pass of the step
-        last_is_syn = real_x is None or not (mt or dft is not None)
-        crnn.run_backward(ctx_s, dx, on_early_grads=self.arena.begin_early if last_is_syn else None)
-        del ctx_s
-        # ---- student on the real batch (+ EMA teacher on its noisy twin)
-        if real_x is not None:
-            if not adv:
+        # (weights are constant until the optimizer step: packed / split copies of a weight tensor are made once and
+        #  shared by the forward and backward passes of the step's batches -- ops.pack_cache)
+        with ops.pack_cache():
+            # ---- student on the synthetic batch: strong + weak BCE
+            crnn.set_seed(step_seed * 4 + 0)
+            enc_s, ctx_s = crnn.run_forward(syn_x, save=True)
+            saved_s = pred.run_forward(enc_s)
+            y_weak_syn = syn_y.max(-2)[0].contiguous()
+            dx, lp = pred.run_backward(enc_s, saved_s, y_strong=syn_y.contiguous(), y_weak=y_weak_syn)
+            out["syn"] = lp
+            dft = None
+            if adv:
+                # domain loss on the SAME encodings (the reference runs a second, numerically identical forward when
+                # dropout is 0 -- SURVEY.md 8d); its feature gradients arrive through the gradient-reverse layer
                 crnn.set_seed(step_seed * 4 + 1)
-                enc_r, ctx_r = crnn.run_forward(real_x, save=mt)
-            saved_r = pred.run_forward(enc_r)
-            if mt:
-                w = self.max_consistency_cost if consistency_cost is None else consistency_cost
-                with torch.no_grad():
-                    self.ema_crnn.train(); self.ema_predictor.train()
-                    self.ema_crnn.set_seed(step_seed * 4 + 2)
-                    enc_e, _ = self.ema_crnn.run_forward(real_x_ema if real_x_ema is not None else real_x, save=False)
-                    strong_e, _, weak_e, _ = self.ema_predictor.run_forward(enc_e)
-                dx, lp = pred.run_backward(enc_r, saved_r, y_weak=real_y_weak.contiguous(), ema_strong=strong_e,
-                                           ema_weak=weak_e, w_cons_s=w, w_cons_w=w)
-                if dft is not None:
-                    ops.axpy(dx, dft)
-                crnn.run_backward(ctx_r, dx, on_early_grads=self.arena.begin_early)
-                out["real"] = lp
-                del ctx_r
-            elif dft is not None:
-                crnn.run_backward(ctx_r, dft.contiguous(), on_early_grads=self.arena.begin_early)
-                del ctx_r
+                enc_r, ctx_r = crnn.run_forward(real_x, save=True)
+                out["domain"] = self.domain_loss(None, enc_s, None, enc_r)
+                dfs, dft = self.domain_loss.backward_features()
+                ops.axpy(dx, dfs)
+            # the gradient exchange starts inside the LAST backward pass of the step
+            last_is_syn = real_x is None or not (mt or dft is not None)
+            crnn.run_backward(ctx_s, dx, on_early_grads=self.arena.begin_early if last_is_syn else None)
+            del ctx_s
+            # ---- student on the real batch (+ EMA teacher on its noisy twin)
+            if real_x is not None:
+                if not adv:
+                    crnn.set_seed(step_seed * 4 + 1)
+                    enc_r, ctx_r = crnn.run_forward(real_x, save=mt)
+                saved_r = pred.run_forward(enc_r)
+                if mt:
+                    w = self.max_consistency_cost if consistency_cost is None else consistency_cost
+                    with torch.no_grad():
+                        self.ema_crnn.train(); self.ema_predictor.train()
+                        self.ema_crnn.set_seed(step_seed * 4 + 2)
+                        enc_e, _ = self.ema_crnn.run_forward(real_x_ema if real_x_ema is not None else real_x, save=False)
+                        strong_e, _, weak_e, _ = self.ema_predictor.run_forward(enc_e)
+                    dx, lp = pred.run_backward(enc_r, saved_r, y_weak=real_y_weak.contiguous(), ema_strong=strong_e,
+                                               ema_weak=weak_e, w_cons_s=w, w_cons_w=w)
+                    if dft is not None:
+                        ops.axpy(dx, dft)
+                    crnn.run_backward(ctx_r, dx, on_early_grads=self.arena.begin_early)
+                    out["real"] = lp
+                    del ctx_r
+                elif dft is not None:
+                    crnn.run_backward(ctx_r, dft.contiguous(), on_early_grads=self.arena.begin_early)
+                    del ctx_r
         # ---- data-parallel gradient exchange + update
         self._all_reduce_grads()
         self.optimizer.step(grad_scale=1.0 / self.world)
@@ -368,51 +371,52 @@ class SEDTrainer:
             enc, ctx = crnn.run_forward(x, save=True)
             return enc, pred.run_forward(enc), ctx
 
-        # base passes (identical to the mean-teacher step)
-        enc_s, sv_s, ctx_s = fwd(syn_x, 0)
-        enc_r, sv_r, ctx_r = fwd(real_x, 1)
-        with torch.no_grad():
-            def teacher(x, slot):
-                ema_c.set_seed(step_seed * 16 + slot)
-                e, _ = ema_c.run_forward(x, save=False)
-                st, _, wk, _ = ema_p.run_forward(e)
-                return st, wk
-            strong_e, weak_e = teacher(real_x_ema, 8)
-            strong_e_sh, _ = teacher(ops.roll(real_x_ema, B, T, F, sh=sh), 9)
-            strong_e_fs, _ = teacher(ops.roll(real_x_ema, B, T, F, sw=sf), 10)
-        strong_r_roll = ops.roll(sv_r[0], B, Tp, C, sh=sp)      # detached by construction
-        strong_s_roll = ops.roll(sv_s[0], B, Tp, C, sh=sp)
-        y_s_roll = ops.roll(syn_y, B, Tp, C, sh=sp)
-        dx, out["syn"] = pred.run_backward(enc_s, sv_s, y_strong=syn_y, y_weak=y_weak_syn)
-        crnn.run_backward(ctx_s, dx)
-        dx, out["real"] = pred.run_backward(enc_r, sv_r, y_weak=real_y_weak.contiguous(), ema_strong=strong_e,
-                                            ema_weak=weak_e, w_cons_s=cc, w_cons_w=cc)
-        crnn.run_backward(ctx_r, dx)
-        del ctx_s, ctx_r
-        # real, time shift: 1/2 cc MSE vs teacher(shifted) + cc/2 MSE vs the rolled (detached) base prediction
-        enc, sv, ctx = fwd(ops.roll(real_x, B, T, F, sh=sh), 2)
-        dx, out["real_shift"] = pred.run_backward(enc, sv, ema_strong=strong_e_sh, w_cons_s=0.5 * cc,
-                                                  ema_strong2=strong_r_roll, w_cons_s2=0.5 * cc)
-        crnn.run_backward(ctx, dx)
-        # real, frequency shift: 1/2 cc MSE vs teacher(freq-shifted); weak BCE on the weakly labelled half only
-        enc, sv, ctx = fwd(ops.roll(real_x, B, T, F, sw=sf), 3)
-        parts, lps = [], []
-        for lo, hi, yw in ((0, half, real_y_weak[:half].contiguous()), (half, B, None)):
-            if hi <= lo:
-                continue
-            d, lp = pred.run_backward(enc[lo:hi], tuple(t[lo:hi] for t in sv), y_weak=yw, ema_strong=strong_e_fs[lo:hi],
-                                      w_cons_s=0.5 * cc, n_strong=n_s, n_weak=max(half, 1) * C)
-            parts.append(d); lps.append(lp)
-        out["real_fshift_weak_half"], out["real_fshift_rest"] = lps[0], lps[-1]
-        crnn.run_backward(ctx, torch.cat(parts, 0))
-        # synthetic, time shift: strong BCE vs the rolled target + cc/2 MSE vs the rolled (detached) base prediction
-        enc, sv, ctx = fwd(ops.roll(syn_x, B, T, F, sh=sh), 4)
-        dx, out["syn_shift"] = pred.run_backward(enc, sv, y_strong=y_s_roll, ema_strong=strong_s_roll, w_cons_s=0.5 * cc)
-        crnn.run_backward(ctx, dx)
-        # synthetic, frequency shift: strong + weak BCE vs the unshifted targets
-        enc, sv, ctx = fwd(ops.roll(syn_x, B, T, F, sw=sf), 5)
-        dx, out["syn_fshift"] = pred.run_backward(enc, sv, y_strong=syn_y, y_weak=y_weak_syn)
-        crnn.run_backward(ctx, dx, on_early_grads=self.arena.begin_early)
+        with ops.pack_cache():   # six student and three teacher passes on unchanged weights: one pack per weight
+            # base passes (identical to the mean-teacher step)
+            enc_s, sv_s, ctx_s = fwd(syn_x, 0)
+            enc_r, sv_r, ctx_r = fwd(real_x, 1)
+            with torch.no_grad():
+                def teacher(x, slot):
+                    ema_c.set_seed(step_seed * 16 + slot)
+                    e, _ = ema_c.run_forward(x, save=False)
+                    st, _, wk, _ = ema_p.run_forward(e)
+                    return st, wk
+                strong_e, weak_e = teacher(real_x_ema, 8)
+                strong_e_sh, _ = teacher(ops.roll(real_x_ema, B, T, F, sh=sh), 9)
+                strong_e_fs, _ = teacher(ops.roll(real_x_ema, B, T, F, sw=sf), 10)
+            strong_r_roll = ops.roll(sv_r[0], B, Tp, C, sh=sp)      # detached by construction
+            strong_s_roll = ops.roll(sv_s[0], B, Tp, C, sh=sp)
+            y_s_roll = ops.roll(syn_y, B, Tp, C, sh=sp)
+            dx, out["syn"] = pred.run_backward(enc_s, sv_s, y_strong=syn_y, y_weak=y_weak_syn)
+            crnn.run_backward(ctx_s, dx)
+            dx, out["real"] = pred.run_backward(enc_r, sv_r, y_weak=real_y_weak.contiguous(), ema_strong=strong_e,
+                                                ema_weak=weak_e, w_cons_s=cc, w_cons_w=cc)
+            crnn.run_backward(ctx_r, dx)
+            del ctx_s, ctx_r
+            # real, time shift: 1/2 cc MSE vs teacher(shifted) + cc/2 MSE vs the rolled (detached) base prediction
+            enc, sv, ctx = fwd(ops.roll(real_x, B, T, F, sh=sh), 2)
+            dx, out["real_shift"] = pred.run_backward(enc, sv, ema_strong=strong_e_sh, w_cons_s=0.5 * cc,
+                                                      ema_strong2=strong_r_roll, w_cons_s2=0.5 * cc)
+            crnn.run_backward(ctx, dx)
+            # real, frequency shift: 1/2 cc MSE vs teacher(freq-shifted); weak BCE on the weakly labelled half only
+            enc, sv, ctx = fwd(ops.roll(real_x, B, T, F, sw=sf), 3)
+            parts, lps = [], []
+            for lo, hi, yw in ((0, half, real_y_weak[:half].contiguous()), (half, B, None)):
+                if hi <= lo:
+                    continue
+                d, lp = pred.run_backward(enc[lo:hi], tuple(t[lo:hi] for t in sv), y_weak=yw, ema_strong=strong_e_fs[lo:hi],
+                                          w_cons_s=0.5 * cc, n_strong=n_s, n_weak=max(half, 1) * C)
+                parts.append(d); lps.append(lp)
+            out["real_fshift_weak_half"], out["real_fshift_rest"] = lps[0], lps[-1]
+            crnn.run_backward(ctx, torch.cat(parts, 0))
+            # synthetic, time shift: strong BCE vs the rolled target + cc/2 MSE vs the rolled (detached) base prediction
+            enc, sv, ctx = fwd(ops.roll(syn_x, B, T, F, sh=sh), 4)
+            dx, out["syn_shift"] = pred.run_backward(enc, sv, y_strong=y_s_roll, ema_strong=strong_s_roll, w_cons_s=0.5 * cc)
+            crnn.run_backward(ctx, dx)
+            # synthetic, frequency shift: strong + weak BCE vs the unshifted targets
+            enc, sv, ctx = fwd(ops.roll(syn_x, B, T, F, sw=sf), 5)
+            dx, out["syn_fshift"] = pred.run_backward(enc, sv, y_strong=syn_y, y_weak=y_weak_syn)
+            crnn.run_backward(ctx, dx, on_early_grads=self.arena.begin_early)
         del ctx
         self._all_reduce_grads()
         self.optimizer.step(grad_scale=1.0 / self.world)

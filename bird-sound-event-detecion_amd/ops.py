@@ -192,23 +192,54 @@ def igemm(inp, wpk, N, NB, H, W, CIN, taps=((0, 0),), bias=None, out=None, epilo
 IGEMM3_RB = {"rb": 1}  # 2 = 256-position tiles where they fit (measured no faster than 1: kept for A-B measurements)
 
 
+_pack_memo = None   # {(kind, data_ptr, args): packed tensor} while an ops.pack_cache() block is open
+
+
+class pack_cache:
+    """Inside this block the caller guarantees that no weight tensor changes (a train step before its optimizer
+    update): a packed / split copy of a weight (pack_weight3, pack_weight3s) is made once per (tensor, layout) and
+    reused by every forward / backward pass in the block -- two half-batch passes of a mean-teacher or adversarial step
+    pack each weight once instead of twice."""
+
+    def __enter__(self):
+        global _pack_memo
+        self._outer = _pack_memo
+        _pack_memo = {} if _pack_memo is None else _pack_memo
+        return self
+
+    def __exit__(self, *exc):
+        global _pack_memo
+        _pack_memo = self._outer
+        return False
+
+
 def pack_weight3(src, ntaps, K, N, s_tap, s_k, s_n):
     """bf16 hi/lo split weights for igemm3: uint16 (ntaps, K/32, NP, 64)"""
+    key = ("w3", src.data_ptr(), L.stream().value, ntaps, K, N, s_tap, s_k, s_n)
+    if _pack_memo is not None and key in _pack_memo:
+        return _pack_memo[key][0]
     NP = round_up(N, 32)
     dst = torch.empty((ntaps, K // 32, NP, 64), device=src.device, dtype=torch.int16)
     _note("pack_weight3_kernel", "", 0.0, 4.0 * dst.numel())
     L.call("bsed_pack_weight3", _fp(_dp(src)), ctypes.c_void_p(dst.data_ptr()), _i(ntaps), _i(K), _i(N), _i(NP),
            ctypes.c_long(s_tap), ctypes.c_long(s_k), ctypes.c_long(s_n), L.stream())
+    if _pack_memo is not None:
+        _pack_memo[key] = (dst, src)   # src kept alive: its address is the key
     return dst
 
 
 def pack_weight3s(src, ntaps, N, s_tap, s_k, s_n, K=16):
     """pre-split weights of a CIN = 16 / 32 convolution in fragment order: int16 (NP/32, ntaps, K/16, 2, 64, 8)"""
+    key = ("w3s", src.data_ptr(), L.stream().value, ntaps, N, s_tap, s_k, s_n, K)
+    if _pack_memo is not None and key in _pack_memo:
+        return _pack_memo[key][0]
     NP = round_up(N, 32)
     dst = torch.empty((NP // 32, ntaps, K // 16, 2, 64, 8), device=src.device, dtype=torch.int16)
     _note("pack_weight3s_kernel", "", 0.0, 4.0 * dst.numel())
     L.call("bsed_pack_weight3s", _fp(_dp(src)), ctypes.c_void_p(dst.data_ptr()), _i(ntaps), _i(K), _i(N), _i(NP),
            ctypes.c_long(s_tap), ctypes.c_long(s_k), ctypes.c_long(s_n), L.stream())
+    if _pack_memo is not None:
+        _pack_memo[key] = (dst, src)   # src kept alive: its address is the key
     return dst
 
 
