@@ -13,8 +13,11 @@ for f in *.hip; do
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ bsed_common.h -nt "$o" ] || [ ../../include/bsed.h -nt "$o" ] \
      || { [ -f igemm_core.h ] && [ igemm_core.h -nt "$o" ]; }; then
     # mel.hip: the SLP vectorizer packs the FFT's scalar fp32 arithmetic into v_pk_* with op_sel swizzles, whose
-    # destination-forwarding hazards cost ~90 s_nop per frame: 0.635 -> 0.599 ms without it (A/B on MI355X)
-    extra=""; [ "$f" = "mel.hip" ] && extra="-fno-slp-vectorize"
+    # destination-forwarding hazards cost ~90 s_nop per frame: 0.635 -> 0.599 ms without it (A/B on MI355X).
+    # The GCN register-pressure trackers let the scheduler see stft_mel2_kernel's real pressure: without them the
+    # default max-occupancy scheduler fills all 256 registers and the allocator spills 16-49 dwords (their reloads sit
+    # behind the prefetched global loads in vmcnt order: 0.655 ms against 0.603 ms spill-free)
+    extra=""; [ "$f" = "mel.hip" ] && extra="-fno-slp-vectorize -mllvm -amdgpu-use-amdgpu-trackers=1"
     $HIPCC $FLAGS $extra -c "$f" -o "$o" &
     pids+=($!)
   fi

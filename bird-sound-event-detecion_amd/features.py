@@ -41,6 +41,7 @@ class MelFrontEnd:
         self._plan = ctypes.c_void_p()
         L.call("bsed_mel_plan_create", ctypes.byref(c), ctypes.byref(self._plan))
         self.nnz = int(L.lib().bsed_mel_plan_nnz(self._plan))
+        self.frames_per_wave = int(L.lib().bsed_mel_plan_frames_per_wave(self._plan))   # 2: stft_mel2_kernel
 
     def __del__(self):
         try:
@@ -64,7 +65,8 @@ class MelFrontEnd:
         sumsq = torch.empty((B, self.cfg.n_mels), device=wav.device, dtype=torch.float32)
         # algorithmic work: wave in + linear mel out; per frame a 2048-point real FFT (2.5 N log2 N), 1025
         # magnitudes and the sparse filterbank
-        ops._note("stft_mel_kernel", f"T{T}", B * T * (2.5 * 2048 * 11 + 4.0 * 1025 + 2.0 * self.nnz),
+        ops._note("stft_mel2_kernel" if self.frames_per_wave == 2 else "stft_mel_kernel", f"T{T}",
+                  B * T * (2.5 * 2048 * 11 + 4.0 * 1025 + 2.0 * self.nnz),
                   4.0 * B * (n + T * self.cfg.n_mels))
         fn = L.lib().bsed_mel_scratch_floats
         fn.restype = ctypes.c_long

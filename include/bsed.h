@@ -45,6 +45,7 @@ typedef struct BsedMelCfg {
 int bsed_mel_plan_create(const BsedMelCfg* cfg /*host*/, void** plan /*host out*/);
 int bsed_mel_plan_destroy(void* plan);
 int bsed_mel_plan_nnz(const void* plan);                    /* non-zeros of the filterbank */
+int bsed_mel_plan_frames_per_wave(const void* plan);        /* 2: bsed_mel_linear runs stft_mel2_kernel (two frames per wave), 1: stft_mel_kernel */
 int bsed_mel_num_frames(const void* plan, int n_samples);   /* 1 + n_samples / hop */
 /* wav (B, n_samples) -> LINEAR mel amplitude (B, T, n_mels) == preprocess(audio).  Also emits the
  * per-clip max (B) and the per-(clip, band) sum over time of x^2 (B, n_mels), which the dB clamp and

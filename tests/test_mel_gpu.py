@@ -49,6 +49,35 @@ def test_linear_mel_matches_oracle(fe, fe_m, seconds, sr):
         np.testing.assert_allclose(sumsq[b], (ref.astype(np.float64) ** 2).sum(0), rtol=1e-4)
 
 
+@pytest.mark.parametrize("sr,n", [(22050, 220500), (32000, 320000), (22050, 4000), (22050, 255 * 10 + 17),
+                                  (22050, 255 * 129 + 100)])
+def test_both_stft_kernels(monkeypatch, sr, n):
+    """stft_mel2_kernel (two frames per wave, the default) and stft_mel_kernel (one frame per wave, BSED_MEL_PAIR=0 and
+    the fallback for filterbanks whose tables do not fit beside eight pair tiles): the same decomposition and operation
+    order per frame, fused multiply-adds chosen independently by the compiler in the two bodies -- they agree to a few
+    ulp of the clip maximum (measured 2.3e-7), so each is held to the oracle bar by the other's test.  Shapes: the bench
+    clip, 32 kHz, a clip of 16 frames that are nearly all edge frames (reflect padding), an odd number of frames (the last
+    pair is half empty), and 130 frames = one workgroup of eight waves plus two frames of a second one."""
+    from bsed_amd.features import MelConfig, MelFrontEnd
+    g = torch.Generator(device="cuda").manual_seed(3)
+    wav = (torch.rand(3, n, device="cuda", generator=g) - 0.5) * torch.tensor([0.1, 0.5, 1.0], device="cuda")[:, None]
+    outs = []
+    for pair in ("1", "0"):
+        monkeypatch.setenv("BSED_MEL_PAIR", pair)
+        fe = MelFrontEnd(MelConfig(sr=sr))
+        assert fe.frames_per_wave == (2 if pair == "1" else 1)
+        outs.append([t.cpu().numpy() for t in fe.linear(wav)])
+    (m2, c2, s2), (m1, c1, s1) = outs
+    for b in range(3):
+        assert np.abs(m2[b] - m1[b]).max() <= 2e-6 * m1[b].max()
+    np.testing.assert_allclose(c2, c1, rtol=2e-6)
+    np.testing.assert_allclose(s2, s1, rtol=1e-5)
+    # bitwise repeatable (fixed-order partial sums, no float atomics)
+    monkeypatch.setenv("BSED_MEL_PAIR", "1")
+    again = [t.cpu().numpy() for t in MelFrontEnd(MelConfig(sr=sr)).linear(wav)]
+    assert all(np.array_equal(a, b) for a, b in zip(again, outs[0]))
+
+
 def test_db_clamp_pad_and_noisy_view(fe):
     wav = _clips(2, 2.0)
     T = 1 + wav.shape[1] // 255
