@@ -172,11 +172,12 @@ class CRNN(_FlatModule):
         self.seed = 0
         self.fused_glu_bwd = True  # False = the unfused 4-launch chain (kept as a cross-check in the tests)
         self.glu3 = os.environ.get("BSED_GLU3", "1") != "0"  # split-fp32 GLU kernels (csrc/glu3.hip)
-        # BSED_RNN_OVERLAP=1: GRU weight gradients of layer l on a side stream, beside the (latency-bound, half-chip)
-        # recurrence of layer l-1: -0.15 .. -0.3 ms per step at B = 256.  Off by default: the overlapped 1-tap weight
-        # gradients are stretched by the recurrence they share the chip with, which would make per-kernel durations
-        # (bench.py's roofline object, rocprof summaries) describe the overlap rather than the kernels.
-        self.overlap_rnn = os.environ.get("BSED_RNN_OVERLAP", "0") == "1"
+        # GRU weight gradients of layer l on a side stream, beside the (latency-bound, half-chip) recurrence of layer
+        # l-1: -0.26 ms per step at B = 256 (14.07 -> 13.81 ms), bitwise identical results (tests/test_fullsize_gpu.py).
+        # The overlapped 1-tap weight gradients are stretched by the recurrence they share the chip with (0.076 ->
+        # 0.167 ms on the hh shapes): ops.KernelTimer counts side-stream launches without timing them, and a rocprof
+        # summary of the default configuration describes the overlap for those rows.  BSED_RNN_OVERLAP=0: one stream.
+        self.overlap_rnn = os.environ.get("BSED_RNN_OVERLAP", "1") != "0"
         # first block without its conv output / gradient tensors in HBM (csrc/block0.hip); 0 = the four-kernel form
         # (conv0_fwd, glu16_fwd, glu16_bwd, conv0_wgrad), kept as the cross-check of the tests
         self.block0_fused = os.environ.get("BSED_BLOCK0_FUSED", "1") != "0"

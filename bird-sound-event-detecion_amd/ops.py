@@ -53,6 +53,8 @@ class KernelTimer:
     def __init__(self):
         self.records = {}  # key -> [flops_per_launch, [(start, end), ...], algorithmic_bytes_per_launch]
         self._last, self._chain = {}, False
+        self._main = ()    # the stream of the first launch (the step's own stream; the null stream reads as None)
+        self.side = {}     # key -> launches on any other stream (not timed: they run beside main-stream kernels)
 
     @staticmethod
     def prime(n=4096):
@@ -70,7 +72,15 @@ class KernelTimer:
         the start of launch i+1 (half the events of a start/end pair per launch: each event costs the GPU ~1.5 us).  A
         launch that follows anything other than a timed launch (the first of a step: host-side work in between) gets
         its own start event."""
-        sid = L.stream().value                      # chains are per stream (side-stream launches overlap the main one)
+        sid = L.stream().value
+        if self._main == ():
+            self._main = sid
+        if sid != self._main:
+            # a side-stream launch (GRU weight gradients beside the next recurrence) shares the chip with main-stream
+            # kernels: an event pair around it would time the queueing, not the kernel.  Counted, not timed.
+            fn()
+            self.side[key] = self.side.get(key, 0) + 1
+            return
         s = self._last.get(sid) if self._chain else None
         if s is None:
             s = torch.cuda.Event(enable_timing=True)
