@@ -175,6 +175,8 @@ def main():
                          "consistency, half the batch synthetic, half real); ada = configs[4] (domain-adversarial head); "
                          "cnn = configs[1] (CNN-only tagging forward, CRNN_pred, batch 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="mel transform inside the step instead of one step ahead on the feature stream")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--timer-steps", type=int, default=10,
                     help="the per-launch HIP events (roofline leg) are recorded during the first N of the timed steps "
@@ -281,17 +283,34 @@ def main():
         tr = SEDTrainer(crnn, pred, optimizer=optimizer, frontend=fe, seed=2023, **extra)
         tr.broadcast_parameters()
         y = strong_labels(ev, Tp, args.sr, mcfg.hop_size, 4, dev)
+        # Two-deep input pipeline (SEDTrainer.train_step(next_waves=...)): the steps alternate between TWO resident
+        # synthetic batches, and each step enqueues the mel transform of the batch the NEXT step trains on (on the
+        # feature stream, beside this step's recurrences).  Every step still transforms one batch -- one step ahead --
+        # and every step trains on a batch other than the previous step's.  --no-pipeline: transform inside the step.
+        wav2, ev2 = synth_waves(B, n, args.sr, 4046 + rank, dev)
+        y2 = strong_labels(ev2, Tp, args.sr, mcfg.hop_size, 4, dev)
+        count = [0]
         if args.mode == "crnn":
+            batches = [(wav, y), (wav2, y2)]
+
             def step():
-                return tr.train_step(wav, y, from_wave=True)
+                (w0, y0), (w1, _) = batches[count[0] % 2], batches[(count[0] + 1) % 2]
+                count[0] += 1
+                return tr.train_step(w0, y0, from_wave=True, next_waves=None if args.no_pipeline else (w1, None))
         else:
             # half the clips play the synthetic (strongly labelled) batch, half the real batch (weak labels for mt)
             h = B // 2
-            wav_s, y_s, wav_r = wav[:h].contiguous(), y[:h].contiguous(), wav[h:].contiguous()
-            yw_r = y[h:].max(1)[0].contiguous() if args.mode == "mt" else None
+            batches = []
+            for w_, y_ in ((wav, y), (wav2, y2)):
+                batches.append((w_[:h].contiguous(), y_[:h].contiguous(), w_[h:].contiguous(),
+                                y_[h:].max(1)[0].contiguous() if args.mode == "mt" else None))
+            del wav2
 
             def step():
-                return tr.train_step(wav_s, y_s, wav_r, yw_r, from_wave=True)
+                b0, b1 = batches[count[0] % 2], batches[(count[0] + 1) % 2]
+                count[0] += 1
+                return tr.train_step(b0[0], b0[1], b0[2], b0[3], from_wave=True,
+                                     next_waves=None if args.no_pipeline else (b1[0], b1[2]))
 
     log(f"data ready: B={B} n={n} T={T} Tp={Tp}")
     use_timer = not args.no_kernel_timer and rank == 0
@@ -360,14 +379,19 @@ def main():
             c, tms, fl, nb = byk[name]
             log("  KERNEL %-40s x%-3d %8.3f ms/step  avg %7.3f ms  %6.1f TFLOP/s %6.0f GB/s" % (
                 name, c // tsteps, tms / tsteps, tms / c, fl / tms / 1e9, nb / tms / 1e6))
-        if timer.side:
-            # launches on the side stream (GRU weight gradients beside the next recurrence) overlap main-stream kernels:
-            # counted, not timed -- their time is inside the step, not in the table
-            log("  not timed (side stream, overlapped): " + ", ".join(
-                "%s x%d" % (k[0], c // tsteps) for k, c in sorted(timer.side.items(), key=lambda kv: kv[0])))
-            extra_side = sum(timer.side.values()) // tsteps
-        else:
-            extra_side = 0
+        # launches on other streams (GRU weight gradients beside the next recurrence; the next batch's mel transform
+        # beside the GRU forward) overlap main-stream kernels: their durations include contention and are listed apart;
+        # their time is inside the step, not in kernels_ms_per_step
+        sside = timer.summary(side=True)
+        byks = {}
+        for k, (c, tms, ams, fl, nb) in sside.items():
+            a = byks.setdefault(k[0], [0, 0.0, 0.0, 0.0])
+            a[0] += c; a[1] += tms; a[2] += fl * c; a[3] += nb * c
+        for nm in sorted(byks, key=lambda n: -byks[n][1]):
+            c, tms, fl, nb = byks[nm]
+            log("  SIDE-STREAM KERNEL (overlapped) %-28s x%-3d %8.3f ms/step  avg %7.3f ms  %6.1f TFLOP/s %6.0f GB/s" % (
+                nm, c // tsteps, tms / tsteps, tms / c, fl / tms / 1e9, nb / tms / 1e6))
+        extra_side = sum(v[0] for v in byks.values()) // tsteps
         name = max(byk, key=lambda n: byk[n][1])
         roofline = kernel_roofline(name, *byk[name])
         roofline["side_stream_launches_not_timed"] = extra_side
@@ -431,7 +455,9 @@ def main():
         "config": {"workload": workload, "mode": args.mode,
                    "clip_seconds": args.seconds, "sr": args.sr, "frames": T, "out_frames": Tp,
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                   "dropout": 0.0 if args.mode == "cnn" else 0.5},
+                   "dropout": 0.0 if args.mode == "cnn" else 0.5,
+                   "input_pipeline": "none" if (args.mode == "cnn" or args.no_pipeline) else
+                   "2 alternating resident batches; each step transforms the next step's waveforms (feature stream)"},
         "roofline": roofline, "cpu_baseline": cpu, "final_loss": round(loss, 5),
     }
     line.update(extra_fields)

@@ -222,6 +222,7 @@ class SEDTrainer:
         self.global_step = 0
         self.seed = seed
         self.pg = process_group
+        self._prefetched, self._feat_stream = {}, None   # train_step(..., next_waves=...): features one step ahead
         self.world = 1
         self.rank = 0
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -245,26 +246,61 @@ class SEDTrainer:
             if getattr(m, "nbt", None) is not None:
                 parallel.broadcast_flat([m.nbt], src, self.pg)
 
-    def _features(self, wav, noisy=False):
+    def _features(self, wav, noisy=False, step=None):
+        pre = self._prefetched.pop(id(wav), None)
+        if pre is not None and pre[0] is wav and pre[1] == (noisy, self.global_step):
+            # computed on the feature stream during the previous step (train_step(..., next_waves=...)): same kernels,
+            # same seed, same values
+            torch.cuda.current_stream().wait_event(pre[3])
+            for t in (pre[2] if isinstance(pre[2], tuple) else (pre[2],)):
+                t.record_stream(torch.cuda.current_stream())
+            return pre[2]
         T = self.frontend.num_frames(wav.shape[1])
         return self.frontend.transform(wav, max_frames=T, noisy=noisy,
-                                       seed=parallel.rank_seed(self.seed, self.global_step, self.rank))
+                                       seed=parallel.rank_seed(self.seed, self.global_step if step is None else step, self.rank))
+
+    def _prefetch_features(self, waves):
+        """Enqueue the NEXT step's waveform -> dB-mel transforms on the feature stream.  Called from the CRNN's
+        recurrence hook: the two GRU layers are latency-bound and occupy half the chip (one workgroup per 4 batch rows),
+        the mel kernels run beside them.  waves: [(wav, noisy), ...]; the caller must leave the waveform tensors
+        untouched until the next train_step has consumed them."""
+        if self._feat_stream is None:
+            self._feat_stream = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        self._feat_stream.wait_stream(main)
+        with torch.cuda.stream(self._feat_stream):
+            for wav, noisy in waves:
+                feats = self._features(wav, noisy=noisy, step=self.global_step + 1)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._prefetched[id(wav)] = (wav, (noisy, self.global_step + 1), feats, ev)
 
     def _all_reduce_grads(self):
         """wait for the early segment's all-reduce (started inside the last backward pass), exchange the tail"""
         self.arena.finish()
 
     def train_step(self, syn_x, syn_y, real_x=None, real_y_weak=None, real_x_ema=None, consistency_cost=None,
-                   from_wave=False):
+                   from_wave=False, next_waves=None):
         """syn_x/real_x: (B,1,T,F) dB-mel batches, or (B,n) waveforms with ``from_wave=True`` (the mel stage then
         runs on the GPU inside the step).  syn_y: (B,T',C) strong targets; real_y_weak: (B,C).
         Mean teacher is active iff EMA models were given AND a real batch is passed.
+        next_waves (with from_wave): ``(next_syn_wav, next_real_wav or None)`` -- the waveforms the NEXT call will be
+        given.  Their mel transforms are enqueued on a second stream while this step's recurrences run (a two-deep
+        input pipeline: every step still transforms one batch, one step ahead); the next call must pass the same
+        tensor objects, unmodified.  Results are bit-identical to the unpipelined step.
         Returns a dict of DEVICE tensors with the per-term loss sums (no host sync)."""
         crnn, pred = self.crnn, self.predictor
         mt = self.ema_crnn is not None and real_x is not None
+        if next_waves is not None and not from_wave:
+            raise L.BsedError("train_step(next_waves=...) prefetches waveform features: it needs from_wave=True")
         if from_wave:
             if self.frontend is None:
                 raise L.BsedError("train_step(from_wave=True) needs a MelFrontEnd")
+            if next_waves is not None:
+                nxt = [(next_waves[0], False)]
+                if len(next_waves) > 1 and next_waves[1] is not None:
+                    nxt.append((next_waves[1], mt and real_x_ema is None))
+                crnn.rnn_hook = lambda: self._prefetch_features(nxt)   # one-shot: fires at the first recurrence
             syn_x = self._features(syn_x)
             if real_x is not None:
                 if mt and real_x_ema is None:

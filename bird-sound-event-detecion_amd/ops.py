@@ -54,7 +54,8 @@ class KernelTimer:
         self.records = {}  # key -> [flops_per_launch, [(start, end), ...], algorithmic_bytes_per_launch]
         self._last, self._chain = {}, False
         self._main = ()    # the stream of the first launch (the step's own stream; the null stream reads as None)
-        self.side = {}     # key -> launches on any other stream (not timed: they run beside main-stream kernels)
+        self.side = {}     # key -> [flops, [(start, end), ...], bytes] of launches on any other stream: they run
+        #                    beside main-stream kernels, so their event pairs time contention (and queueing) as well
 
     @staticmethod
     def prime(n=4096):
@@ -76,10 +77,15 @@ class KernelTimer:
         if self._main == ():
             self._main = sid
         if sid != self._main:
-            # a side-stream launch (GRU weight gradients beside the next recurrence) shares the chip with main-stream
-            # kernels: an event pair around it would time the queueing, not the kernel.  Counted, not timed.
+            # a side-stream launch (GRU weight gradients beside the next recurrence, the next batch's mel transform
+            # beside the GRU forward) shares the chip with main-stream kernels: its own event pair, kept apart from
+            # the main-stream table (summary(side=True))
+            s = torch.cuda.Event(enable_timing=True)
+            s.record()
             fn()
-            self.side[key] = self.side.get(key, 0) + 1
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.side.setdefault(key, [flops, [], nbytes])[1].append((s, e))
             return
         s = self._last.get(sid) if self._chain else None
         if s is None:
@@ -96,10 +102,10 @@ class KernelTimer:
         """call between steps (or around host-side work): the next launch records its own start event"""
         self._chain = False
 
-    def summary(self):
+    def summary(self, side=False):
         """{key: (launches, total_ms, avg_ms, flops_per_launch, bytes_per_launch)} -- call after a device sync"""
         out = {}
-        for key, (flops, evs, nbytes) in self.records.items():
+        for key, (flops, evs, nbytes) in (self.side if side else self.records).items():
             ms = [s.elapsed_time(e) for s, e in evs]
             out[key] = (len(ms), float(sum(ms)), float(sum(ms) / len(ms)), flops, nbytes)
         return out

@@ -104,6 +104,48 @@ def test_from_waveform_step_is_the_composition_of_mel_and_crnn_at_full_size():
     assert torch.equal(losses[0][1], losses[1][1])
 
 
+@pytest.mark.parametrize("mt", [False, True])
+def test_feature_pipeline_gives_the_same_steps(mt):
+    """train_step(..., next_waves=...): the next step's mel transform runs one step ahead on the feature stream (beside
+    the recurrences).  Three steps over two alternating batches, pipelined and not: the same losses and bit-identical
+    weights after every step -- also with the mean teacher, whose noisy teacher view is seeded by the step it belongs to."""
+    from bsed_amd.engine import FlatAdam, SEDTrainer
+    from bsed_amd.features import MelConfig, MelFrontEnd
+    from bsed_amd.models import CRNN, Predictor
+    sr, nb = 22050, 6
+    rng = np.random.default_rng(21)
+    fe = MelFrontEnd(MelConfig(sr=sr))
+    Tp = fe.num_frames(4 * sr) // 4
+    data = []
+    for k in range(2):
+        ws = torch.from_numpy((0.1 * rng.standard_normal((nb, 4 * sr))).astype(np.float32)).cuda()
+        wr = torch.from_numpy((0.1 * rng.standard_normal((nb, 4 * sr))).astype(np.float32)).cuda()
+        ys = torch.from_numpy(seeded.strong_targets(30 + k, nb, Tp)).cuda()
+        data.append((ws, ys, wr if mt else None, ys.max(1)[0].contiguous() if mt else None))
+    runs = []
+    for pipelined in (False, True):
+        crnn, pred = _models(0.5)
+        extra = {}
+        if mt:
+            kw = dict(co.CRNN_KWARGS); kw["dropout"] = 0.5
+            ema_c, ema_p = CRNN(**kw), Predictor(**co.PREDICTOR_KWARGS)
+            ema_c.load_state_dict(crnn.state_dict()); ema_p.load_state_dict(pred.state_dict())
+            extra = dict(ema_crnn=ema_c, ema_predictor=ema_p)
+        tr = SEDTrainer(crnn, pred, optimizer=FlatAdam([crnn, pred], lr=1e-3), frontend=fe, seed=11, **extra)
+        trace = []
+        for i in range(3):
+            ws, ys, wr, yw = data[i % 2]
+            nxt = data[(i + 1) % 2]
+            out = tr.train_step(ws, ys, wr, yw, from_wave=True, next_waves=(nxt[0], nxt[2]) if pipelined else None)
+            trace.append((SEDTrainer.loss_value(out), crnn.flat.clone(), pred.flat.clone()))
+        if pipelined:
+            assert len(tr._prefetched) == (2 if mt else 1)    # the fourth step's features are waiting
+        runs.append(trace)
+    for (la, ca, pa), (lb, cb, pb) in zip(*runs):
+        assert la == lb
+        assert torch.equal(ca, cb) and torch.equal(pa, pb)
+
+
 def test_train_step_is_bitwise_repeatable_at_full_size():
     """Two runs from the same state give bit-identical gradients (dropout on): every reduction in the path is ordered
     (partial slabs + fixed-order sums, no float atomics on the CRNN path).  This check found a VALU -> MFMA SrcC
