@@ -37,23 +37,31 @@ def synth_waves(B, n, sr, seed, device):
     tones/chirps per clip with random onset/offset; returns (wave (B,n), events[(on,off,cls)] per clip)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     t = torch.arange(n, device=device, dtype=torch.float32) / sr
+    idx = torch.arange(n, device=device)
     y = 0.1 * torch.randn((B, n), generator=torch.Generator(device=device).manual_seed(seed), device=device)
     dur = n / sr
-    ev = []
     par = torch.rand((B, 3, 6), generator=g)
-    for b in range(B):
-        evb = []
-        for e in range(3):
+    ev = [[] for _ in range(B)]
+    for e in range(3):   # one event per clip at a time, all clips at once (a few dozen launches instead of thousands)
+        cols = {k: [] for k in ("f0", "f1", "amp", "on", "off", "i0", "i1")}
+        for b in range(B):
             f0 = 500 + float(par[b, e, 0]) * (sr / 2 - 1000)
             f1 = 500 + float(par[b, e, 1]) * (sr / 2 - 1000) if float(par[b, e, 2]) < 0.5 else f0
             amp = 0.05 + 0.45 * float(par[b, e, 3])
             on = float(par[b, e, 4]) * (dur - 0.2)
             off = on + 0.2 + float(par[b, e, 5]) * (dur - on - 0.2)
-            i0, i1 = int(on * sr), min(n, int(off * sr))
-            tt = t[i0:i1] - on
-            y[b, i0:i1] += amp * torch.sin(2 * np.pi * (f0 * tt + 0.5 * (f1 - f0) * tt * tt / (off - on)))
-            evb.append((on, off, int(par[b, e, 2] * 1e6) % 20))
-        ev.append(evb)
+            for k, v in (("f0", f0), ("f1", f1), ("amp", amp), ("on", on), ("off", off), ("i0", int(on * sr)),
+                         ("i1", min(n, int(off * sr)))):
+                cols[k].append(v)
+            ev[b].append((on, off, int(par[b, e, 2] * 1e6) % 20))
+        c = {k: torch.tensor(v, device=device, dtype=torch.int64 if k in ("i0", "i1") else torch.float32)[:, None]
+             for k, v in cols.items()}
+        for lo in range(0, B, 32):   # 32 clips at a time: the temporaries stay below 0.3 GB
+            sl = slice(lo, min(B, lo + 32))
+            tt = t[None, :] - c["on"][sl]
+            chirp = c["amp"][sl] * torch.sin(2 * np.pi * (c["f0"][sl] * tt + 0.5 * (c["f1"][sl] - c["f0"][sl]) * tt * tt
+                                                         / (c["off"][sl] - c["on"][sl])))
+            y[sl] += chirp * ((idx[None, :] >= c["i0"][sl]) & (idx[None, :] < c["i1"][sl]))
     return y.clamp_(-1, 1), ev
 
 
