@@ -17,6 +17,8 @@ but the first two CNN blocks' has been enqueued, and overlaps the rest of it; th
 the optimizer kernel.
 """
 import numpy as np
+import os
+
 import torch
 
 from . import _lib as L
@@ -223,6 +225,9 @@ class SEDTrainer:
         self.seed = seed
         self.pg = process_group
         self._prefetched, self._feat_stream = {}, None   # train_step(..., next_waves=...): features one step ahead
+        # mean teacher: the EMA pair's forward on its own stream beside the student's passes (BSED_TEACHER_OVERLAP=0: inline)
+        self.teacher_overlap = os.environ.get("BSED_TEACHER_OVERLAP", "1") != "0"
+        self._teacher_stream = None
         self.world = 1
         self.rank = 0
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -275,6 +280,13 @@ class SEDTrainer:
                 ev.record()
                 self._prefetched[id(wav)] = (wav, (noisy, self.global_step + 1), feats, ev)
 
+    def _teacher_forward(self, x, step_seed):
+        self.ema_crnn.train(); self.ema_predictor.train()
+        self.ema_crnn.set_seed(step_seed * 4 + 2)
+        enc_e, _ = self.ema_crnn.run_forward(x, save=False)
+        strong_e, _, weak_e, _ = self.ema_predictor.run_forward(enc_e)
+        return strong_e, weak_e
+
     def _all_reduce_grads(self):
         """wait for the early segment's all-reduce (started inside the last backward pass), exchange the tail"""
         self.arena.finish()
@@ -317,6 +329,20 @@ class SEDTrainer:
         B, Tp, C = syn_y.shape
         # (weights are constant until the optimizer step: packed / split copies of a weight tensor are made once and
         #  shared by the forward and backward passes of the step's batches -- ops.pack_cache)
+        teacher = None
+        if mt and self.teacher_overlap:
+            # The EMA teacher's forward depends on nothing the student computes in this step: it is enqueued on its own
+            # stream NOW and fills the chip beside the student's latency-bound kernels (recurrences, small launches);
+            # the consistency loss of the real batch waits for its event.  Same kernels, same inputs: same bits.
+            if self._teacher_stream is None:
+                self._teacher_stream = torch.cuda.Stream()
+            main = torch.cuda.current_stream()
+            self._teacher_stream.wait_stream(main)       # features and last step's EMA update are ordered before it
+            with torch.cuda.stream(self._teacher_stream), torch.no_grad(), ops.pack_cache():
+                strong_e, weak_e = self._teacher_forward(real_x_ema if real_x_ema is not None else real_x, step_seed)
+                ev = torch.cuda.Event()
+                ev.record()
+            teacher = (strong_e, weak_e, ev)
         with ops.pack_cache():
             # ---- student on the synthetic batch: strong + weak BCE
             crnn.set_seed(step_seed * 4 + 0)
@@ -346,11 +372,15 @@ class SEDTrainer:
                 saved_r = pred.run_forward(enc_r)
                 if mt:
                     w = self.max_consistency_cost if consistency_cost is None else consistency_cost
-                    with torch.no_grad():
-                        self.ema_crnn.train(); self.ema_predictor.train()
-                        self.ema_crnn.set_seed(step_seed * 4 + 2)
-                        enc_e, _ = self.ema_crnn.run_forward(real_x_ema if real_x_ema is not None else real_x, save=False)
-                        strong_e, _, weak_e, _ = self.ema_predictor.run_forward(enc_e)
+                    if teacher is not None:
+                        strong_e, weak_e, ev = teacher
+                        torch.cuda.current_stream().wait_event(ev)
+                        strong_e.record_stream(torch.cuda.current_stream())
+                        weak_e.record_stream(torch.cuda.current_stream())
+                    else:
+                        with torch.no_grad():
+                            strong_e, weak_e = self._teacher_forward(real_x_ema if real_x_ema is not None else real_x,
+                                                                     step_seed)
                     dx, lp = pred.run_backward(enc_r, saved_r, y_weak=real_y_weak.contiguous(), ema_strong=strong_e,
                                                ema_weak=weak_e, w_cons_s=w, w_cons_w=w)
                     if dft is not None:

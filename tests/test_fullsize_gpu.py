@@ -108,7 +108,8 @@ def test_from_waveform_step_is_the_composition_of_mel_and_crnn_at_full_size():
 def test_feature_pipeline_gives_the_same_steps(mt):
     """train_step(..., next_waves=...): the next step's mel transform runs one step ahead on the feature stream (beside
     the recurrences).  Three steps over two alternating batches, pipelined and not: the same losses and bit-identical
-    weights after every step -- also with the mean teacher, whose noisy teacher view is seeded by the step it belongs to."""
+    weights after every step -- also with the mean teacher, whose noisy teacher view is seeded by the step it belongs to
+    and whose forward then runs on its own stream beside the student's passes (SEDTrainer.teacher_overlap)."""
     from bsed_amd.engine import FlatAdam, SEDTrainer
     from bsed_amd.features import MelConfig, MelFrontEnd
     from bsed_amd.models import CRNN, Predictor
@@ -132,6 +133,7 @@ def test_feature_pipeline_gives_the_same_steps(mt):
             ema_c.load_state_dict(crnn.state_dict()); ema_p.load_state_dict(pred.state_dict())
             extra = dict(ema_crnn=ema_c, ema_predictor=ema_p)
         tr = SEDTrainer(crnn, pred, optimizer=FlatAdam([crnn, pred], lr=1e-3), frontend=fe, seed=11, **extra)
+        tr.teacher_overlap = pipelined     # the EMA teacher's forward on its own stream beside the student's passes
         trace = []
         for i in range(3):
             ws, ys, wr, yw = data[i % 2]
