@@ -17,6 +17,10 @@ n_fft//2, frames at hop, window multiply in float64, rfft, result stored complex
 filters.mel(htk=False, norm=None) Slaney scale, float32 basis; melspectrogram(S=...)
 = basis @ S in float32; amplitude_to_db = power_to_db(S**2, amin**2) with the
 top_db clamp against the per-array max.
+
+Second source (not a pin): tests/test_mel_oracle_crosscheck_cpu.py compares this file with
+transformers.audio_utils (a numpy port of librosa) and scipy.signal.stft / torch.stft at
+both configurations of the path.
 """
 import numpy as np
 
