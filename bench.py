@@ -345,13 +345,14 @@ def main():
         if timer is not None and i == tsteps:
             ops.set_timer(None)     # the remaining timed steps run without per-launch events
         out = step()
+    host_enqueue = time.perf_counter() - t0     # the host is done enqueueing; the GPU may still be running
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.set_timer(None)
-    log(f"timed region done: {elapsed:.3f}s for {args.steps} steps")
+    log(f"timed region done: {elapsed:.3f}s for {args.steps} steps (host enqueue {1e3 * host_enqueue / args.steps:.2f} ms/step)")
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)

@@ -256,23 +256,27 @@ void igemm3_kernel(const Igemm3Params P) {
 }
 
 // w3[tap][chunk][n][0..31] = bf16 hi, [32..63] = bf16 lo of src[tap*s_tap + (chunk*32+k)*s_k + n*s_n]; zero for n >= N
+__device__ __forceinline__ void pack3_elem(const float* __restrict__ src, unsigned short* __restrict__ dst, long e,
+                                           int nchunks, int N, int NP, long s_tap, long s_k, long s_n) {
+  const int k = (int)(e & 31);
+  long r = e >> 5;
+  const int n = (int)(r % NP); r /= NP;
+  const int ch = (int)(r % nchunks);
+  const int tap = (int)(r / nchunks);
+  const float v = n < N ? src[tap * s_tap + (long)(ch * 32 + k) * s_k + n * s_n] : 0.f;
+  const unsigned short hi = f2bf(v);
+  const unsigned short lo = f2bf(v - bf2f(hi));
+  unsigned short* d = dst + (((long)tap * nchunks + ch) * NP + n) * 64;
+  d[k] = hi;
+  d[32 + k] = lo;
+}
+
 __global__ void pack_weight3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int ntaps, int K,
                                     int N, int NP, long s_tap, long s_k, long s_n) {
   const int nchunks = K / 32;
   const long total = (long)ntaps * nchunks * NP * 32;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(e & 31);
-    long r = e >> 5;
-    const int n = (int)(r % NP); r /= NP;
-    const int ch = (int)(r % nchunks);
-    const int tap = (int)(r / nchunks);
-    const float v = n < N ? src[tap * s_tap + (long)(ch * 32 + k) * s_k + n * s_n] : 0.f;
-    const unsigned short hi = f2bf(v);
-    const unsigned short lo = f2bf(v - bf2f(hi));
-    unsigned short* d = dst + (((long)tap * nchunks + ch) * NP + n) * 64;
-    d[k] = hi;
-    d[32 + k] = lo;
-  }
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+    pack3_elem(src, dst, e, nchunks, N, NP, s_tap, s_k, s_n);
 }
 
 // fragment-layout self test of v_mfma_f32_32x32x16_bf16: C(32,32) = A(32,K) B(K,32) with bf16x3 split operands
@@ -323,25 +327,49 @@ extern "C" int bsed_pack_weight3(const float* src, void* dst, int ntaps, int K, 
 // BatchNorm partial sums accumulate in registers over the tiles of a workgroup (one partial row per workgroup).
 // (KS = CIN / 16 K steps per tap: 1 for the 16 -> 32 convolution, 2 for the data gradients of 32-channel layers)
 
+// table[jn][tap][kk][hi|lo][lane][8]: lane (li, lh) holds k = 16*kk + 8*lh + q of output channel n = 32*jn + li
+__device__ __forceinline__ void pack3s_elem(const float* __restrict__ src, unsigned short* __restrict__ dst, long e,
+                                            int ntaps, int KS, int N, long s_tap, long s_k, long s_n) {
+  const int lane = (int)(e & 63), li = lane & 31, lh = lane >> 5;
+  long r = e >> 6;
+  const int kk = (int)(r % KS); r /= KS;
+  const int tap = (int)(r % ntaps), jn = (int)(r / ntaps);
+  const int n = 32 * jn + li;
+  unsigned short* d = dst + (((((long)jn * ntaps + tap) * KS + kk) * 2) * 64 + lane) * 8;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float v = n < N ? src[tap * s_tap + (long)(16 * kk + 8 * lh + q) * s_k + n * s_n] : 0.f;
+    const unsigned short hi = f2bf(v);
+    d[q] = hi;
+    d[64 * 8 + q] = f2bf(v - bf2f(hi));
+  }
+}
+
 __global__ void pack_weight3s_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int ntaps, int KS,
                                      int N, int NP, long s_tap, long s_k, long s_n) {
-  // table[jn][tap][kk][hi|lo][lane][8]: lane (li, lh) holds k = 16*kk + 8*lh + q of output channel n = 32*jn + li
   const long total = (long)(NP / 32) * ntaps * KS * 64;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int lane = (int)(e & 63), li = lane & 31, lh = lane >> 5;
-    long r = e >> 6;
-    const int kk = (int)(r % KS); r /= KS;
-    const int tap = (int)(r % ntaps), jn = (int)(r / ntaps);
-    const int n = 32 * jn + li;
-    unsigned short* d = dst + (((((long)jn * ntaps + tap) * KS + kk) * 2) * 64 + lane) * 8;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float v = n < N ? src[tap * s_tap + (long)(16 * kk + 8 * lh + q) * s_k + n * s_n] : 0.f;
-      const unsigned short hi = f2bf(v);
-      d[q] = hi;
-      d[64 * 8 + q] = f2bf(v - bf2f(hi));
-    }
-  }
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+    pack3s_elem(src, dst, e, ntaps, KS, N, s_tap, s_k, s_n);
+}
+
+// Every weight re-layout of a train step in ONE launch (the packs are 5-7 us kernels on the forward's critical path:
+// fourteen launches cost ~0.19 ms per step in event time).  Same per-element code as the two kernels above: same bits.
+struct PkJob {
+  const float* src; unsigned short* dst;
+  int kind, ntaps, KS, N, NP, wg0;   // kind 0: pack_weight3 layout (KS = K / 32 chunks), 1: pack_weight3s (KS = K / 16)
+  long total, s_tap, s_k, s_n;
+};
+struct PkBatch { PkJob j[BSED_PACK_MAX_JOBS]; int njobs; };
+
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PkBatch Bt) {
+  int ji = 0;
+  for (int k = 1; k < Bt.njobs; ++k)
+    if ((int)blockIdx.x >= Bt.j[k].wg0) ji = k;
+  const PkJob& J = Bt.j[ji];
+  const long e = (long)((int)blockIdx.x - J.wg0) * 256 + threadIdx.x;
+  if (e >= J.total) return;
+  if (J.kind == 0) pack3_elem(J.src, J.dst, e, J.KS, J.N, J.NP, J.s_tap, J.s_k, J.s_n);
+  else pack3s_elem(J.src, J.dst, e, J.ntaps, J.KS, J.N, J.s_tap, J.s_k, J.s_n);
 }
 
 // NV = output channels a workgroup really has (32, or 16 for N <= 16): with 16 the plain epilogue would store 64-byte
@@ -654,6 +682,29 @@ extern "C" int bsed_igemm3s(const BsedIgemmDesc* desc, int G, void* stream) {
   else I3S_LAUNCH(1, 2);
 #undef I3S_LAUNCH
 #undef I3S_LAUNCH1
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_pack_weights_batch(const BsedPackJob* jobs, int njobs, void* stream) {
+  BSED_CHECK_ARG(jobs && njobs > 0 && njobs <= BSED_PACK_MAX_JOBS, "bsed_pack_weights_batch: 1..%d jobs", BSED_PACK_MAX_JOBS);
+  PkBatch Bt;
+  Bt.njobs = njobs;
+  long wg = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const BsedPackJob& q = jobs[i];
+    BSED_CHECK_ARG(q.src && q.dst && q.ntaps > 0 && q.K > 0 && q.N > 0 && q.NP >= q.N && q.NP % 32 == 0 &&
+                   (q.kind == 0 ? q.K % 32 == 0 : (q.kind == 1 && q.K % 16 == 0)), "bsed_pack_weights_batch: bad job %d", i);
+    PkJob& J = Bt.j[i];
+    J.src = q.src; J.dst = (unsigned short*)q.dst; J.kind = q.kind; J.ntaps = q.ntaps; J.N = q.N; J.NP = q.NP;
+    J.s_tap = q.s_tap; J.s_k = q.s_k; J.s_n = q.s_n;
+    if (q.kind == 0) { J.KS = q.K / 32; J.total = (long)q.ntaps * J.KS * q.NP * 32; }
+    else { J.KS = q.K / 16; J.total = (long)(q.NP / 32) * q.ntaps * J.KS * 64; }
+    J.wg0 = (int)wg;
+    wg += ceil_div(J.total, 256);
+    BSED_CHECK_ARG(wg < (1L << 31), "bsed_pack_weights_batch: too many workgroups");
+  }
+  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)wg), dim3(256), 0, (hipStream_t)stream, Bt);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }

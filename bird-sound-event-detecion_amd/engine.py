@@ -228,6 +228,9 @@ class SEDTrainer:
         # mean teacher: the EMA pair's forward on its own stream beside the student's passes (BSED_TEACHER_OVERLAP=0: inline)
         self.teacher_overlap = os.environ.get("BSED_TEACHER_OVERLAP", "1") != "0"
         self._teacher_stream = None
+        # the packed weight copies a step needs, made in ONE launch at its start from the second step on
+        # (ops.PackPlan; BSED_PACK_PLAN=0: one launch per weight at first use, the pre-plan behaviour)
+        self._pack_plans = {} if os.environ.get("BSED_PACK_PLAN", "1") != "0" else None
         self.world = 1
         self.rank = 0
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -237,6 +240,11 @@ class SEDTrainer:
         disc = domain_loss.domain_discriminator if domain_loss is not None else None
         self.arena = parallel.GradArena([crnn, predictor, disc], tail_floats=crnn.tail_grad_floats(),
                                         group=process_group)
+
+    def _plan(self, which):
+        if self._pack_plans is None:
+            return None
+        return self._pack_plans.setdefault(which, ops.PackPlan())
 
     def broadcast_parameters(self, src=0):
         """identical initial weights / statistics on every rank"""
@@ -338,12 +346,12 @@ class SEDTrainer:
                 self._teacher_stream = torch.cuda.Stream()
             main = torch.cuda.current_stream()
             self._teacher_stream.wait_stream(main)       # features and last step's EMA update are ordered before it
-            with torch.cuda.stream(self._teacher_stream), torch.no_grad(), ops.pack_cache():
+            with torch.cuda.stream(self._teacher_stream), torch.no_grad(), ops.pack_cache(self._plan("teacher")):
                 strong_e, weak_e = self._teacher_forward(real_x_ema if real_x_ema is not None else real_x, step_seed)
                 ev = torch.cuda.Event()
                 ev.record()
             teacher = (strong_e, weak_e, ev)
-        with ops.pack_cache():
+        with ops.pack_cache(self._plan("step")):
             # ---- student on the synthetic batch: strong + weak BCE
             crnn.set_seed(step_seed * 4 + 0)
             enc_s, ctx_s = crnn.run_forward(syn_x, save=True)
@@ -437,7 +445,7 @@ class SEDTrainer:
             enc, ctx = crnn.run_forward(x, save=True)
             return enc, pred.run_forward(enc), ctx
 
-        with ops.pack_cache():   # six student and three teacher passes on unchanged weights: one pack per weight
+        with ops.pack_cache(self._plan("isp")):   # six student and three teacher passes on unchanged weights: one pack per weight
             # base passes (identical to the mean-teacher step)
             enc_s, sv_s, ctx_s = fwd(syn_x, 0)
             enc_r, sv_r, ctx_r = fwd(real_x, 1)

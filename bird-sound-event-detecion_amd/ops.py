@@ -209,53 +209,141 @@ IGEMM3_RB = {"rb": 1}  # 2 = 256-position tiles where they fit (measured no fast
 
 
 _pack_memo = None   # {(kind, data_ptr, args): packed tensor} while an ops.pack_cache() block is open
+_pack_plan = None   # the PackPlan of the open outermost block, if it was given one
+
+
+class BsedPackJob(ctypes.Structure):
+    _fields_ = ([("src", _fp), ("dst", ctypes.c_void_p)]
+                + [(n, _i) for n in ("kind", "ntaps", "K", "N", "NP")]
+                + [(n, ctypes.c_long) for n in ("s_tap", "s_k", "s_n")])
+
+
+PACK_MAX_JOBS = 32   # BSED_PACK_MAX_JOBS
+
+
+class PackPlan:
+    """Which packed weight copies a recurring ``pack_cache`` block asked for last time.  The next block given the same
+    plan makes ALL of them in one launch on entry (``bsed_pack_weights_batch``) instead of one 5-7 us launch per weight
+    on the forward's and backward's critical path (fourteen per CRNN train step).  Entries a block did not use are
+    dropped when it closes; new requests are packed on the spot and join the plan.  Same kernels' element code: same
+    bits as the unplanned path (tests/test_pack_plan_gpu.py)."""
+
+    def __init__(self):
+        self.entries = {}     # key -> (kind, src, ntaps, K, N, s_tap, s_k, s_n)
+        self.used = set()
+
+    @staticmethod
+    def _numel(kind, ntaps, K, N):
+        NP = round_up(N, 32)
+        return ntaps * (K // 32) * NP * 64 if kind == 0 else (NP // 32) * ntaps * (K // 16) * 2 * 64 * 8
+
+    def replay(self, memo):
+        stream = L.stream()
+        todo = [(k, v) for k, v in self.entries.items() if k[2] == stream.value]
+        self.used = set()
+        if not todo:
+            return
+        dev = todo[0][1][1].device
+        sizes = [self._numel(v[0], v[2], v[3], v[4]) for _, v in todo]
+        buf = torch.empty(sum(sizes), device=dev, dtype=torch.int16)
+        _note("pack_weights_batch_kernel", "", 0.0, 4.0 * buf.numel())
+        off = 0
+        jobs = []
+        for (key, (kind, src, ntaps, K, N, s_tap, s_k, s_n)), n in zip(todo, sizes):
+            NP = round_up(N, 32)
+            shape = (ntaps, K // 32, NP, 64) if kind == 0 else (NP // 32, ntaps, K // 16, 2, 64, 8)
+            dst = buf[off:off + n].view(shape)
+            off += n
+            memo[key] = (dst, src)
+            jobs.append((src.data_ptr(), dst.data_ptr(), kind, ntaps, K, N, NP, s_tap, s_k, s_n))
+        for j0 in range(0, len(jobs), PACK_MAX_JOBS):
+            part = jobs[j0:j0 + PACK_MAX_JOBS]
+            arr = (BsedPackJob * len(part))()
+            for a, (sp, dp, kind, ntaps, K, N, NP, s_tap, s_k, s_n) in zip(arr, part):
+                a.src = sp; a.dst = dp
+                a.kind, a.ntaps, a.K, a.N, a.NP = kind, ntaps, K, N, NP
+                a.s_tap, a.s_k, a.s_n = s_tap, s_k, s_n
+            L.call("bsed_pack_weights_batch", arr, _i(len(part)), stream)
+
+    def close(self):
+        stream = L.stream().value
+        for k in [k for k in self.entries if k[2] == stream and k not in self.used]:
+            del self.entries[k]
 
 
 class pack_cache:
     """Inside this block the caller guarantees that no weight tensor changes (a train step before its optimizer
     update): a packed / split copy of a weight (pack_weight3, pack_weight3s) is made once per (tensor, layout) and
     reused by every forward / backward pass in the block -- two half-batch passes of a mean-teacher or adversarial step
-    pack each weight once instead of twice."""
+    pack each weight once instead of twice.  With a ``PackPlan`` (a block that recurs, e.g. the train step) the copies
+    the previous block used are all made in one launch on entry."""
+
+    def __init__(self, plan=None):
+        self._plan = plan
 
     def __enter__(self):
-        global _pack_memo
+        global _pack_memo, _pack_plan
         self._outer = _pack_memo
-        _pack_memo = {} if _pack_memo is None else _pack_memo
+        self._outer_plan = _pack_plan
+        if _pack_memo is None:
+            _pack_memo = {}
+            _pack_plan = self._plan
+            if _pack_plan is not None:
+                _pack_plan.replay(_pack_memo)
         return self
 
     def __exit__(self, *exc):
-        global _pack_memo
+        global _pack_memo, _pack_plan
+        if self._outer is None and _pack_plan is not None:
+            _pack_plan.close()
         _pack_memo = self._outer
+        _pack_plan = self._outer_plan
         return False
+
+
+def _pack_lookup(key):
+    if _pack_memo is not None and key in _pack_memo:
+        if _pack_plan is not None:
+            _pack_plan.used.add(key)
+        return _pack_memo[key][0]
+    return None
+
+
+def _pack_store(key, dst, src, kind, ntaps, K, N, s_tap, s_k, s_n):
+    if _pack_memo is not None:
+        _pack_memo[key] = (dst, src)   # src kept alive: its address is the key
+        if _pack_plan is not None:
+            _pack_plan.entries[key] = (kind, src, ntaps, K, N, s_tap, s_k, s_n)
+            _pack_plan.used.add(key)
 
 
 def pack_weight3(src, ntaps, K, N, s_tap, s_k, s_n):
     """bf16 hi/lo split weights for igemm3: uint16 (ntaps, K/32, NP, 64)"""
     key = ("w3", src.data_ptr(), L.stream().value, ntaps, K, N, s_tap, s_k, s_n)
-    if _pack_memo is not None and key in _pack_memo:
-        return _pack_memo[key][0]
+    hit = _pack_lookup(key)
+    if hit is not None:
+        return hit
     NP = round_up(N, 32)
     dst = torch.empty((ntaps, K // 32, NP, 64), device=src.device, dtype=torch.int16)
     _note("pack_weight3_kernel", "", 0.0, 4.0 * dst.numel())
     L.call("bsed_pack_weight3", _fp(_dp(src)), ctypes.c_void_p(dst.data_ptr()), _i(ntaps), _i(K), _i(N), _i(NP),
            ctypes.c_long(s_tap), ctypes.c_long(s_k), ctypes.c_long(s_n), L.stream())
-    if _pack_memo is not None:
-        _pack_memo[key] = (dst, src)   # src kept alive: its address is the key
+    _pack_store(key, dst, src, 0, ntaps, K, N, s_tap, s_k, s_n)
     return dst
 
 
 def pack_weight3s(src, ntaps, N, s_tap, s_k, s_n, K=16):
     """pre-split weights of a CIN = 16 / 32 convolution in fragment order: int16 (NP/32, ntaps, K/16, 2, 64, 8)"""
     key = ("w3s", src.data_ptr(), L.stream().value, ntaps, N, s_tap, s_k, s_n, K)
-    if _pack_memo is not None and key in _pack_memo:
-        return _pack_memo[key][0]
+    hit = _pack_lookup(key)
+    if hit is not None:
+        return hit
     NP = round_up(N, 32)
     dst = torch.empty((NP // 32, ntaps, K // 16, 2, 64, 8), device=src.device, dtype=torch.int16)
     _note("pack_weight3s_kernel", "", 0.0, 4.0 * dst.numel())
     L.call("bsed_pack_weight3s", _fp(_dp(src)), ctypes.c_void_p(dst.data_ptr()), _i(ntaps), _i(K), _i(N), _i(NP),
            ctypes.c_long(s_tap), ctypes.c_long(s_k), ctypes.c_long(s_n), L.stream())
-    if _pack_memo is not None:
-        _pack_memo[key] = (dst, src)   # src kept alive: its address is the key
+    _pack_store(key, dst, src, 1, ntaps, K, N, s_tap, s_k, s_n)
     return dst
 
 

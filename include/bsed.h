@@ -128,6 +128,17 @@ int bsed_pack_weight3(const float* src, void* dst, int ntaps, int K, int N, int 
  * w = bsed_pack_weight3s table ((NP/32) * ntaps * (K/16) * 2 * 64 * 16 bytes); STATS writes G partial rows (one per workgroup). */
 int bsed_pack_weight3s(const float* src, void* dst, int ntaps, int K, int N, int NP, long s_tap, long s_k, long s_n,
                        void* stream);
+/* several bsed_pack_weight3 (kind 0) / bsed_pack_weight3s (kind 1) re-layouts in one launch: the weights of a train step
+ * are constant until its optimizer update, so every packed copy the step needs can be made at its start (same bits as the
+ * single-job entries; the reference has no counterpart: its convolutions read the PyTorch weight tensors directly,
+ * src/models/CNN.py:46-47) */
+#define BSED_PACK_MAX_JOBS 32
+typedef struct BsedPackJob {
+  const float* src; void* dst;
+  int kind, ntaps, K, N, NP;
+  long s_tap, s_k, s_n;
+} BsedPackJob;
+int bsed_pack_weights_batch(const BsedPackJob* jobs /*host*/, int njobs, void* stream);
 int bsed_igemm3s(const BsedIgemmDesc* desc, int G, void* stream);
 int bsed_igemm3s_auto_g(void);
 int bsed_igemm3s_auto_g2(int CIN, int N);   /* per shape (resident workgroups differ with the LDS footprint) */
