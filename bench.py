@@ -21,6 +21,9 @@ import re
 import sys
 import time
 
+# hardware queues for the step's streams + RCCL's (bsed_amd/_lib.py sets the same default; here before torch is imported)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 

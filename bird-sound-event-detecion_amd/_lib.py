@@ -7,6 +7,14 @@ import ctypes
 import os
 import re
 
+# The train step keeps up to four HIP streams busy (main, GRU weight gradients, the next batch's mel transform, the EMA
+# teacher) and RCCL adds its own.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4):
+# beyond that two streams share a queue and their kernels serialise, which takes the overlap back -- measured on one
+# MI355X box, same process otherwise: 13.28 ms per step; 13.63 once an RCCL communicator exists; 13.31 with 8 queues
+# (DESIGN.md section 7).  Read by the runtime when it initialises, so it is set at import, before the first HIP call;
+# an explicit setting in the environment wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSED_LIB_PATH") or os.path.join(_HERE, "libbsed.so")  # override: A/B experiment builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bsed.h")
