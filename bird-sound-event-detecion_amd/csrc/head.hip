@@ -135,6 +135,36 @@ __global__ void head_weak_kernel(const float* __restrict__ part, float* __restri
   den_out[i] = den;
 }
 
+// weak (clip-level) targets of the train loop: out[b][c] = max_t y[b][t][c]  (reference src/main_baseline.py:
+// ``target_weak = target.max(-2)[0]`` inside train_mt, once per batch).  One workgroup per clip; a 4.4 MB read that
+// torch's generic reduction spends 50 us on (one 64-thread workgroup per five output columns).
+#define MT_THREADS 256
+__global__ __launch_bounds__(MT_THREADS) void max_over_time_kernel(const float* __restrict__ y, float* __restrict__ out,
+                                                                  int T, int C) {
+  __shared__ float red[MT_THREADS];
+  const int tid = threadIdx.x, b_ = blockIdx.x;
+  const int groups = MT_THREADS / C;            // time phases handled side by side
+  const int c = tid % C, ph = tid / C;
+  float m = -INFINITY;
+  if (ph < groups) {
+    const float* col = y + (size_t)b_ * T * C + c;
+    for (int t = ph; t < T; t += groups) m = fmaxf(m, col[(size_t)t * C]);
+  }
+  red[tid] = m;
+  __syncthreads();
+  if (tid < C) {
+    for (int g = 1; g < groups; ++g) m = fmaxf(m, red[g * C + tid]);
+    out[(size_t)b_ * C + tid] = m;
+  }
+}
+
+extern "C" int bsed_max_over_time(const float* y, float* out, int B, int T, int C, void* stream) {
+  BSED_CHECK_ARG(y && out && B > 0 && T > 0 && C > 0 && C <= MT_THREADS, "bsed_max_over_time: bad argument (C <= %d)", MT_THREADS);
+  hipLaunchKernelGGL(max_over_time_kernel, dim3(B), dim3(MT_THREADS), 0, (hipStream_t)stream, y, out, T, C);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
 // BCE element (PyTorch semantics): value with log clamped at -100
 __device__ __forceinline__ float bce_val(float s, float y) {
   return -(y * fmaxf(logf(s), -100.f) + (1.f - y) * fmaxf(logf(1.f - s), -100.f));

@@ -356,7 +356,7 @@ class SEDTrainer:
             crnn.set_seed(step_seed * 4 + 0)
             enc_s, ctx_s = crnn.run_forward(syn_x, save=True)
             saved_s = pred.run_forward(enc_s)
-            y_weak_syn = syn_y.max(-2)[0].contiguous()
+            y_weak_syn = ops.max_over_time(syn_y)
             dx, lp = pred.run_backward(enc_s, saved_s, y_strong=syn_y.contiguous(), y_weak=y_weak_syn)
             out["syn"] = lp
             dft = None
@@ -436,7 +436,7 @@ class SEDTrainer:
         self.arena.zero_()
         syn_x, real_x, real_x_ema = syn_x.contiguous(), real_x.contiguous(), real_x_ema.contiguous()
         syn_y = syn_y.contiguous()
-        y_weak_syn = syn_y.max(-2)[0].contiguous()
+        y_weak_syn = ops.max_over_time(syn_y)
         n_s, n_w = B * Tp * C, B * C
         out = {"shape": (B, Tp, C)}
 

@@ -849,6 +849,16 @@ def gru_bwd(dout, out, gates, w_hh, B, T, mode="fp32"):
     return dxp, dgh, None, None
 
 
+def max_over_time(y):
+    """(B,T,C) -> (B,C) maximum over time (weak targets of the train loop: ``target.max(-2)[0]``)"""
+    y = y.contiguous().float()
+    B, T, C = y.shape
+    out = torch.empty((B, C), device=y.device, dtype=torch.float32)
+    _note("max_over_time_kernel", f"T{T}", 0.0, 4.0 * (y.numel() + out.numel()))
+    L.call("bsed_max_over_time", L.ptr(y), L.ptr(out), _i(B), _i(T), _i(C), L.stream())
+    return out
+
+
 def head_fwd(x, w, b, B, T, K, C, attention):
     dev = x.device
     strong = torch.empty((B, T, C), device=dev, dtype=torch.float32)

@@ -395,6 +395,9 @@ int bsed_gru_bwd3_rows(int B);
  * and the BCE / MSE loss assembly of train_mt (src/main_baseline.py:431-498).
  *   w (2C,K): rows 0..C-1 = dense.weight, rows C..2C-1 = dense_softmax.weight; b (2C) likewise.
  * ---------------------------------------------------------------------------------------------- */
+/* out (B,C) = max over time of y (B,T,C): the clip-level targets the train loop derives from the strong ones
+ * (src/main_baseline.py train_mt: target_weak = target.max(-2)[0]) */
+int bsed_max_over_time(const float* y, float* out, int B, int T, int C, void* stream);
 /* The head kernels split each clip's frames over S = bsed_head_splits(B, T) workgroups.  bsed_head_fwd needs a
  * (B,S,2,C) scratch buffer `part` when S > 1; bsed_head_bwd writes S rows per clip into its partial outputs
  * (dw_part (B*S,2C,K), db_part (B*S,2C), loss_part (B*S,6)): sum over the leading dimension as before. */
