@@ -189,10 +189,10 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="mel transform inside the step instead of one step ahead on the feature stream")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--timer-steps", type=int, default=10,
+    ap.add_argument("--timer-steps", type=int, default=4,
                     help="the per-launch HIP events (roofline leg) are recorded during the first N of the timed steps "
-                         "(0 = all of them): each event costs the GPU ~1.5 us, 2-3 %% of a step when every launch of every "
-                         "step carries one")
+                         "(0 = all of them): an evented step is ~0.3 ms (2 %%) longer -- measured at --steps 20: 13.54 ms "
+                         "without events, 13.59 / 13.63 / 13.71 with 3 / 5 / 10 evented steps; the kernel averages agree")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 64 if args.mode == "cnn" else 256

@@ -53,7 +53,13 @@ class KernelTimer:
     def __init__(self):
         self.records = {}  # key -> [flops_per_launch, [(start, end), ...], algorithmic_bytes_per_launch]
         self._last, self._chain = {}, False
-        self._main = ()    # the stream of the first launch (the step's own stream; the null stream reads as None)
+        # the step's own stream = the stream that is current when the timer is made (the null stream reads as None).
+        # (Taking the stream of the first LAUNCH instead made the mean-teacher step's table name the teacher's stream
+        # "main": its forward is the first thing a step enqueues.)
+        try:
+            self._main = L.stream().value
+        except Exception:
+            self._main = ()    # no GPU yet: fall back to the stream of the first launch
         self.side = {}     # key -> [flops, [(start, end), ...], bytes] of launches on any other stream: they run
         #                    beside main-stream kernels, so their event pairs time contention (and queueing) as well
 
