@@ -336,7 +336,9 @@ def main():
         log(f"warmup step {i} done")
     timer = None
     if use_timer:
-        timer = ops.KernelTimer()
+        # (the mean-teacher step runs on a high-priority stream of the trainer: that is the step's "main" stream)
+        own = getattr(tr, "_step_stream", None) if tr is not None else None
+        timer = ops.KernelTimer(main_stream=own.cuda_stream) if own is not None else ops.KernelTimer()
         ops.set_timer(timer)
     torch.cuda.synchronize()
     if world > 1:

@@ -50,16 +50,21 @@ class KernelTimer:
     the kernel's name as rocprofv3 prints it (template instance included) so that bench.py's table and the committed
     rocprof summary can be joined by name."""
 
-    def __init__(self):
+    def __init__(self, main_stream=()):
         self.records = {}  # key -> [flops_per_launch, [(start, end), ...], algorithmic_bytes_per_launch]
         self._last, self._chain = {}, False
         # the step's own stream = the stream that is current when the timer is made (the null stream reads as None).
         # (Taking the stream of the first LAUNCH instead made the mean-teacher step's table name the teacher's stream
         # "main": its forward is the first thing a step enqueues.)
-        try:
-            self._main = L.stream().value
-        except Exception:
-            self._main = ()    # no GPU yet: fall back to the stream of the first launch
+        # main_stream: the raw handle (``torch.cuda.Stream.cuda_stream``) of the stream the step runs on when that is not
+        # the caller's (SEDTrainer runs the mean-teacher step on a high-priority stream of its own).
+        if main_stream != ():
+            self._main = main_stream or None
+        else:
+            try:
+                self._main = L.stream().value
+            except Exception:
+                self._main = ()    # no GPU yet: fall back to the stream of the first launch
         self.side = {}     # key -> [flops, [(start, end), ...], bytes] of launches on any other stream: they run
         #                    beside main-stream kernels, so their event pairs time contention (and queueing) as well
 
