@@ -172,6 +172,20 @@ __global__ void bn_eval_kernel(int C, float eps, const float* __restrict__ gamma
   shift[c] = beta[c] - running_mean[c] * sc;
 }
 
+// the eval-mode scale / shift of every BatchNorm layer of a forward in one launch (blockIdx.y = layer)
+struct BnEvalBatch {
+  struct { const float *gamma, *beta, *rmean, *rvar; float *scale, *shift; int C; } j[BSED_BN_EVAL_MAX_JOBS];
+  float eps;
+};
+__global__ void bn_eval_batch_kernel(const BnEvalBatch Bt) {
+  const auto& J = Bt.j[blockIdx.y];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= J.C) return;
+  const float sc = J.gamma[c] / sqrtf(J.rvar[c] + Bt.eps);   // same expression as bn_eval_kernel: same bits
+  J.scale[c] = sc;
+  J.shift[c] = J.beta[c] - J.rmean[c] * sc;
+}
+
 // sums = (sum g, sum g*y) -> dgamma, dbeta and the coefficients of d_y = A g + B (y - mean) + Cc
 __global__ void bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ coef,
                                     const float* __restrict__ mean, long n4, int C) {
@@ -419,6 +433,24 @@ extern "C" int bsed_bn_eval(int C, float eps, const float* gamma, const float* b
   BSED_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && C > 0, "bsed_bn_eval: bad argument");
   hipLaunchKernelGGL(bn_eval_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, (hipStream_t)stream, C, eps, gamma, beta,
                      running_mean, running_var, scale, shift);
+  BSED_LAUNCH_CHECK();
+  return BSED_OK;
+}
+
+extern "C" int bsed_bn_eval_batch(const BsedBnEvalJob* jobs, int njobs, float eps, void* stream) {
+  BSED_CHECK_ARG(jobs && njobs > 0 && njobs <= BSED_BN_EVAL_MAX_JOBS, "bsed_bn_eval_batch: 1..%d jobs", BSED_BN_EVAL_MAX_JOBS);
+  BnEvalBatch Bt;
+  Bt.eps = eps;
+  int cmax = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const BsedBnEvalJob& q = jobs[i];
+    BSED_CHECK_ARG(q.gamma && q.beta && q.running_mean && q.running_var && q.scale && q.shift && q.C > 0,
+                   "bsed_bn_eval_batch: bad job %d", i);
+    Bt.j[i].gamma = q.gamma; Bt.j[i].beta = q.beta; Bt.j[i].rmean = q.running_mean; Bt.j[i].rvar = q.running_var;
+    Bt.j[i].scale = q.scale; Bt.j[i].shift = q.shift; Bt.j[i].C = q.C;
+    cmax = std::max(cmax, q.C);
+  }
+  hipLaunchKernelGGL(bn_eval_batch_kernel, dim3(ceil_div(cmax, 128), njobs), dim3(128), 0, (hipStream_t)stream, Bt);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }

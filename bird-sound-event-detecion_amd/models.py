@@ -183,6 +183,8 @@ class CRNN(_FlatModule):
         self.block0_fused = os.environ.get("BSED_BLOCK0_FUSED", "1") != "0"
         self._side_stream = None
         self.rnn_hook = None
+        # eval-mode forwards (get_predictions, the CNN-only tagger): the packed weight copies of a forward in one launch
+        self._eval_plan = ops.PackPlan()
         # "bf16x3" (default): the 3x3 conv forward / data-gradient contractions and the GRU projection GEMMs run on the
         # bf16 matrix cores with split-fp32 operands (csrc/igemm3.hip; measured 5.5e-6 on the logits of the reference
         # config, 18x inside the 1e-4 bar).  "fp32": exact fp32 matrix cores everywhere (9.6e-7 on the logits).
@@ -300,14 +302,14 @@ class CRNN(_FlatModule):
                 g[o[f"{base}bias_hh_l{l}"]:o[f"{base}bias_hh_l{l}"] + 6 * H])
 
     # ------------------------------------------------------------------ building blocks
-    def _block_forward(self, a, B, Hh, Ww, cin, co, pool, names, drop, rng_stream, nbt, train, first=False):
+    def _block_forward(self, a, B, Hh, Ww, cin, co, pool, names, drop, rng_stream, nbt, train, first=False, bn_pre=None):
         """conv3x3 -> BatchNorm -> GLU -> Dropout -> AvgPool (reference src/models/CNN.py:46-67).  names = (conv, bn,
         glu-linear) parameter prefixes.  Returns (pooled, saved-for-backward dict)."""
         ph, pw = pool
         cw, cb = self.P(names[0] + ".weight"), self.P(names[0] + ".bias")
         taps, wsrc, s_tap = self._conv_taps(cw, Ww)
         if first and co == 16 and self.block0_fused and 1 < Ww <= 256 and B * Hh * Ww < (1 << 31):
-            return self._block0_forward(a, B, Hh, Ww, pool, names, drop, rng_stream, nbt, train)
+            return self._block0_forward(a, B, Hh, Ww, pool, names, drop, rng_stream, nbt, train, bn_pre)
         if first:
             y, stats = ops.conv0_fwd(a, cw, cb, B, Hh, Ww, co, want_stats=train)
         else:
@@ -327,7 +329,7 @@ class CRNN(_FlatModule):
                                                          bn.weight, bn.bias, bn.running_mean, bn.running_var, nbt)
         else:
             mean = invstd = None
-            scale, shift = ops.bn_eval(co, BN_EPS, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+            scale, shift = bn_pre or ops.bn_eval(co, BN_EPS, bn.weight, bn.bias, bn.running_mean, bn.running_var)
         glu = self.P(names[2])
         if co == 16:
             # 4 FLOP/B: HBM-bound streaming kernel instead of the MFMA tile kernel (csrc/glu_small.hip)
@@ -345,7 +347,7 @@ class CRNN(_FlatModule):
                    pool=(ph, pw), names=names, drop=drop, rng=rng_stream, first=first)
         return pooled, blk
 
-    def _block0_forward(self, a, B, Hh, Ww, pool, names, drop, rng_stream, nbt, train):
+    def _block0_forward(self, a, B, Hh, Ww, pool, names, drop, rng_stream, nbt, train, bn_pre=None):
         """the first block with its conv output recomputed where needed instead of stored (csrc/block0.hip): batch
         statistics from x alone, then conv + BN + GLU + dropout + pool in one pass x -> pooled"""
         cw, cb = self.P(names[0] + ".weight"), self.P(names[0] + ".bias")
@@ -357,7 +359,7 @@ class CRNN(_FlatModule):
                                                          bn.weight, bn.bias, bn.running_mean, bn.running_var, nbt)
         else:
             mean = invstd = None
-            scale, shift = ops.bn_eval(16, BN_EPS, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+            scale, shift = bn_pre or ops.bn_eval(16, BN_EPS, bn.weight, bn.bias, bn.running_mean, bn.running_var)
         pooled = ops.block0_fwd(a, cw, cb, scale, shift, glu.weight, glu.bias, B, Hh, Ww, pool, drop, rng_stream,
                                 self.seed)
         blk = dict(inp=a, y=None, xr64=xr64, mean=mean, invstd=invstd, scale=scale, shift=shift, H=Hh, W=Ww, cin=1,
@@ -559,13 +561,19 @@ class CRNN(_FlatModule):
         train = self.training
         drop = self.dropout_p if train else 0.0
         a, cin = x, 1
+        bn_pre = None
+        if not train and len(self.nb_filters) <= 16:
+            # eval mode: the running-statistics scale / shift of all blocks in one launch
+            bns = [self.P(f"cnn.batchnorm{i}") for i in range(len(self.nb_filters))]
+            bn_pre = ops.bn_eval_batch([(co, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+                                        for co, bn in zip(self.nb_filters, bns)], BN_EPS)
         for i, co in enumerate(self.nb_filters):
             ph, pw = self.pooling[i]
             if Ww % pw or Ww < 2 and pw > 1:
                 raise L.BsedError(f"block {i}: width {Ww} not divisible by the pooling window")
             names = (f"cnn.conv{i}", f"cnn.batchnorm{i}", f"cnn.glu{i}.linear")
             a, blk = self._block_forward(a, B, Hh, Ww, cin, co, (ph, pw), names, drop, 100 + i, self.nbt[i:i + 1],
-                                         train, first=(i == 0))
+                                         train, first=(i == 0), bn_pre=None if bn_pre is None else bn_pre[i])
             if ctx is not None:
                 ctx["blocks"].append(blk)
             cin = co
@@ -599,8 +607,9 @@ class CRNN(_FlatModule):
         train = self.training
         drop = self.dropout_p if train else 0.0
         ctx = {"B": B, "blocks": [], "train": train, "seed": self.seed, "x": x} if save else None
-        a, T = self._cnn_forward(x, ctx)
-        seq, layers = self._gru_forward(a.view(B, T, self.nb_filters[-1]), B, T, "rnn", save)
+        with ops.pack_cache(None if train else self._eval_plan):
+            a, T = self._cnn_forward(x, ctx)
+            seq, layers = self._gru_forward(a.view(B, T, self.nb_filters[-1]), B, T, "rnn", save)
         enc = ops.dropout(seq, drop, 200, self.seed) if drop > 0 else seq
         if save:
             ctx.update(T=T, layers=layers, drop=drop)
@@ -815,16 +824,17 @@ class CRNN_pred(CRNN):
             raise L.BsedError(f"CRNN_pred expects (B,1,T,F), got {tuple(x.shape)}")
         x = x.contiguous().float()
         B = x.shape[0]
-        a, T = self._cnn_forward(x, None)
-        C = self.nclass
-        feats = a.view(B, T, C)
-        w, b = self.P("dense_softmax.weight"), self.P("dense_softmax.bias")
-        if self.conv_mode == "bf16x3":
-            w3 = ops.pack_weight3(w, 1, C, C, 0, 1, C)
-            logits, _ = ops.igemm3(feats, w3, C, 1, B * T, 1, C, ((0, 0),), bias=b)
-        else:
-            wpk = ops.pack_weight(w, 1, C, C, 0, 1, C)
-            logits, _ = ops.igemm(feats, wpk, C, 1, B * T, 1, C, bias=b)
+        with ops.pack_cache(None if self.training else self._eval_plan):
+            a, T = self._cnn_forward(x, None)
+            C = self.nclass
+            feats = a.view(B, T, C)
+            w, b = self.P("dense_softmax.weight"), self.P("dense_softmax.bias")
+            if self.conv_mode == "bf16x3":
+                w3 = ops.pack_weight3(w, 1, C, C, 0, 1, C)
+                logits, _ = ops.igemm3(feats, w3, C, 1, B * T, 1, C, ((0, 0),), bias=b)
+            else:
+                wpk = ops.pack_weight(w, 1, C, C, 0, 1, C)
+                logits, _ = ops.igemm(feats, wpk, C, 1, B * T, 1, C, bias=b)
         return ops.tag_head_fwd(feats, logits.view(B, T, C))
 
     def run_backward(self, ctx, d):

@@ -777,6 +777,27 @@ def bn_eval(C, eps, gamma, beta, rmean, rvar):
     return scale, shift
 
 
+class BsedBnEvalJob(ctypes.Structure):
+    _fields_ = [(n, _fp) for n in ("gamma", "beta", "running_mean", "running_var", "scale", "shift")] + [("C", _i)]
+
+
+def bn_eval_batch(layers, eps):
+    """[(C, gamma, beta, running_mean, running_var), ...] -> [(scale, shift), ...] in one launch (eval-mode forward)"""
+    dev = layers[0][1].device
+    out = torch.empty(2 * sum(l[0] for l in layers), device=dev, dtype=torch.float32)
+    arr = (BsedBnEvalJob * len(layers))()
+    res, off = [], 0
+    for a, (C, gamma, beta, rmean, rvar) in zip(arr, layers):
+        scale, shift = out[off:off + C], out[off + C:off + 2 * C]
+        off += 2 * C
+        a.gamma, a.beta, a.running_mean, a.running_var = _dp(gamma), _dp(beta), _dp(rmean), _dp(rvar)
+        a.scale, a.shift, a.C = scale.data_ptr(), shift.data_ptr(), C
+        res.append((scale, shift))
+    _note("bn_eval_batch_kernel", "", 0.0, 4.0 * 3 * out.numel())
+    L.call("bsed_bn_eval_batch", arr, _i(len(layers)), ctypes.c_float(eps), L.stream())
+    return res
+
+
 def bn_bwd(stats, C, count, gamma, mean, invstd, dgamma, dbeta, g_inout, y, apply=True):
     """apply=False: only dgamma/dbeta and the (3,C) coefficients [A|B|C] of d_y = A g + B (y-mean) + C (returned);
     the consumer applies the map on load (conv0_wgrad)."""

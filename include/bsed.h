@@ -221,6 +221,14 @@ int bsed_bn_finalize(const float* partial, long ntiles, int C, double count, flo
 /* eval mode: scale/shift from the running statistics */
 int bsed_bn_eval(int C, float eps, const float* gamma, const float* beta, const float* running_mean,
                  const float* running_var, float* scale, float* shift, void* stream);
+/* the same for every BatchNorm layer of an eval-mode forward in one launch */
+#define BSED_BN_EVAL_MAX_JOBS 16
+typedef struct BsedBnEvalJob {
+  const float *gamma, *beta, *running_mean, *running_var;
+  float *scale, *shift;
+  int C;
+} BsedBnEvalJob;
+int bsed_bn_eval_batch(const BsedBnEvalJob* jobs /*host*/, int njobs, float eps, void* stream);
 /* BatchNorm backward: partial = per-tile (sum g, sum g*y); writes dgamma/dbeta and turns g (n_elems,
  * NHWC, in place) into d_y = A g + B (y - mean) + C;  coef (3,C) receives [A | B | C].  g_inout = y = NULL:
  * coefficients only (the consumer applies the map on load). */
