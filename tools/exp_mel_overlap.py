@@ -44,14 +44,31 @@ def run(name, step, K=30):
 
 
 def step_b():
+    crnn.rnn_hook = hook     # one-shot in the model: re-armed for every step
     out = tr.train_step(inp, y)
     torch.cuda.current_stream().wait_stream(side)
     return out
 
 
 run("A mel inside the step", lambda: tr.train_step(wav, y, from_wave=True))
-crnn.rnn_hook = hook
 run("B mel on the side stream beside the GRU forward", step_b)
 crnn.rnn_hook = None
 run("C no mel at all (bound)", lambda: tr.train_step(inp, y))
 run("A again", lambda: tr.train_step(wav, y, from_wave=True))
+
+# D: the trainer's own two-deep pipeline (train_step(next_waves=...)) over two alternating batches, as bench.py runs it
+wav2, ev2 = bench.synth_waves(B, n, 22050, 4046, dev)
+y2 = bench.strong_labels(ev2, T // 4, 22050, mcfg.hop_size, 4, dev)
+batches = [(wav, y), (wav2, y2)]
+cnt = [0]
+
+
+def step_d():
+    (w0, y0), (w1, _) = batches[cnt[0] % 2], batches[(cnt[0] + 1) % 2]
+    cnt[0] += 1
+    return tr.train_step(w0, y0, from_wave=True, next_waves=(w1, None))
+
+
+run("D trainer pipeline, two alternating batches", step_d)
+run("C again", lambda: tr.train_step(inp, y))
+run("D again", step_d)
