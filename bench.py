@@ -189,6 +189,9 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="mel transform inside the step instead of one step ahead on the feature stream")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.5,
+                    help="dropout of the CRNN (0.5 = the reference's crnn_kwargs and the BASELINE configuration; other values "
+                         "are diagnostic: 0 shows what the mask hashes and the final dropout kernels cost)")
     ap.add_argument("--timer-steps", type=int, default=4,
                     help="the per-launch HIP events (roofline leg) are recorded during the first N of the timed steps "
                          "(0 = all of them): an evented step is ~0.3 ms (2 %%) longer -- measured at --steps 20: 13.54 ms "
@@ -252,7 +255,7 @@ def main():
     from bsed_amd.models import CRNN, CRNN_pred, Predictor, weights_init
 
     kw = dict(n_in_channel=1, nclass=20, attention=True, n_RNN_cell=128, n_layers_RNN=2, activation="glu",
-              dropout=0.5, kernel_size=7 * [3], padding=7 * [1], stride=7 * [1],
+              dropout=args.dropout, kernel_size=7 * [3], padding=7 * [1], stride=7 * [1],
               nb_filters=[16, 32, 64, 128, 128, 128, 128],
               pooling=[[2, 2], [2, 2], [1, 2], [1, 2], [1, 2], [1, 2], [1, 2]])
     torch.manual_seed(2023)
@@ -469,7 +472,7 @@ def main():
         "config": {"workload": workload, "mode": args.mode,
                    "clip_seconds": args.seconds, "sr": args.sr, "frames": T, "out_frames": Tp,
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                   "dropout": 0.0 if args.mode == "cnn" else 0.5,
+                   "dropout": 0.0 if args.mode == "cnn" else args.dropout,
                    "input_pipeline": "none" if (args.mode == "cnn" or args.no_pipeline) else
                    "2 alternating resident batches; each step transforms the next step's waveforms (feature stream)"},
         "roofline": roofline, "cpu_baseline": cpu, "final_loss": round(loss, 5),

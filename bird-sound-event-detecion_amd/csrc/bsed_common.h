@@ -114,6 +114,9 @@ __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn
 // in forward and backward.  (Philox stays for the Gaussian SNR noise.)
 // ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+#ifdef BSED_DIAG_NOHASH   // diagnostic builds only (tools/build_variant.sh): what the mask hashes cost; masks are WRONG
+  return x;
+#endif
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
