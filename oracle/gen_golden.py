@@ -21,7 +21,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = "/root/reference/src"
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("BSED_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")   # tools/check_golden.py redirects
 sys.path.insert(0, ROOT)
 sys.path.insert(0, REF)
 
@@ -223,8 +223,9 @@ def clipd_case():
 
 
 def init_case():
+    torch.manual_seed(1)            # construction draws (the GRU biases keep them: weights_init skips 1-D GRU tensors)
     crnn, pred = CRNN(**CRNN_KWARGS), Predictor(**PREDICTOR_KWARGS)
-    torch.manual_seed(2023)         # seeded AFTER construction: the draws below are weights_init's alone
+    torch.manual_seed(2023)         # re-seeded AFTER construction: the draws below are weights_init's alone
     crnn.apply(weights_init)
     pred.apply(weights_init)
     stats = {}
@@ -356,8 +357,9 @@ def transforms_case():
 def fpn_init_case():
     """per-tensor statistics of the reference's CRNN_fpn after .apply(weights_init) (utilities/utils.py:40-63)"""
     from models.CRNN_GRL import CRNN_fpn as RefFPN
+    torch.manual_seed(1)            # construction draws (GRU biases), see init_case
     m = RefFPN(**CRNN_KWARGS)
-    torch.manual_seed(2023)         # seeded AFTER construction: the draws below are weights_init's alone
+    torch.manual_seed(2023)         # re-seeded AFTER construction: the draws below are weights_init's alone
     m.apply(weights_init)
     stats = {}
     for k, v in m.state_dict().items():
@@ -426,6 +428,96 @@ def cnn_pred_case():
     print("wrote cnn_pred.npz", {k: getattr(v, "shape", None) for k, v in g.items()})
 
 
+def isp_case():
+    """One ``-mt -ISP`` iteration of train_mt, re-assembled from the IMPORTED reference CRNN / Predictor with the
+    reference's own per-sample torch.roll loops and loss composition (src/main_baseline.py:229-277 batch views,
+    :337-420 forwards and rolled predictions / targets, :442-529 loss).  Written against the script, not against
+    oracle/crnn_oracle.train_losses_isp, which this fixture pins (tests/test_oracle_golden.py) together with the HIP
+    step (tests/test_crnn_gpu.py).  Same seeds / sizes as that GPU test: B = 4 + 4, T = 128."""
+    seed, B, T = 41, 4, 128
+    rng = np.random.default_rng(seed)
+    xs = seeded.db_like_input(seed + 1, B, T); xr = seeded.db_like_input(seed + 2, B, T)
+    xe = xr + rng.normal(0, 1.0, xr.shape).astype(np.float32)
+    y = seeded.strong_targets(seed + 3, B, T // 4)
+    yw = (rng.random((B, 20)) < 0.2).astype(np.float32)
+    shift_list, freq_shift_list = [-8, 12, 0, 40], [3, -2, 0, -4]     # randint(-64,64)*4 / randint(-4,4) draws
+    cc = 0.6                                                          # cfg.max_consistency_cost * rampup_value
+    model, predictor, c1, c2 = build(0.0, seed)
+    ema_model, ema_predictor, c3, c4 = build(0.0, seed + 5)
+    for m in (model, predictor, ema_model, ema_predictor):
+        m.train()
+    for p in list(ema_model.parameters()) + list(ema_predictor.parameters()):
+        p.detach_()
+    class_criterion, consistency_criterion = torch.nn.BCELoss(), torch.nn.MSELoss()
+    syn_batch_input, syn_target = t(xs), t(y)
+    batch_input, ema_batch_input, target_weak = t(xr), t(xe), t(yw)
+    pooling_time_ratio = 4
+    views = {}
+    for name, src in (("batch", batch_input), ("ema", ema_batch_input), ("syn", syn_batch_input)):
+        sh, fs = [], []
+        for k in range(batch_input.shape[0]):                          # :233-246 (sample k is (1, T, F))
+            sh.append(torch.unsqueeze(torch.roll(src[k], shift_list[k], dims=1), 0))
+            fs.append(torch.unsqueeze(torch.roll(src[k], freq_shift_list[k], dims=2), 0))
+        views[name + "_shift"], views[name + "_freq_shift"] = torch.cat(sh, 0), torch.cat(fs, 0)
+    syn_encoded_x, _ = model(syn_batch_input)                          # :337-341
+    syn_strong_pred, syn_weak_pred = predictor(syn_encoded_x)
+    encoded_x, _ = model(batch_input)
+    strong_pred, weak_pred = predictor(encoded_x)
+    strong_pred_ema, weak_pred_ema = [v.detach() for v in ema_predictor(ema_model(ema_batch_input)[0])]   # :352-356
+    strong_pred_shift_ema = ema_predictor(ema_model(views["ema_shift"])[0])[0].detach()                   # :360-363
+    strong_pred_freq_shift_ema = ema_predictor(ema_model(views["ema_freq_shift"])[0])[0].detach()         # :365-368
+    sp, ssp, sts = [], [], []
+    for k in range(strong_pred.shape[0]):                              # :374-401
+        pool_shift = int(shift_list[k] / pooling_time_ratio)
+        sp.append(torch.unsqueeze(torch.roll(strong_pred[k], pool_shift, dims=0), 0))
+        ssp.append(torch.unsqueeze(torch.roll(syn_strong_pred[k], pool_shift, dims=0), 0))
+        sts.append(torch.unsqueeze(torch.roll(syn_target[k], pool_shift, dims=0), 0))
+    strong_pred_shift, syn_strong_pred_shift = torch.cat(sp, 0).detach(), torch.cat(ssp, 0).detach()
+    syn_strong_target_shift = torch.cat(sts, 0)
+    strong_shift_pred, weak_shift_pred = predictor(model(views["batch_shift"])[0])                        # :408-419
+    strong_freq_shift_pred, weak_freq_shift_pred = predictor(model(views["batch_freq_shift"])[0])
+    syn_strong_shift_pred, _ = predictor(model(views["syn_shift"])[0])
+    syn_strong_freq_shift_pred, syn_weak_freq_shift_pred = predictor(model(views["syn_freq_shift"])[0])
+    syn_target_weak = syn_target.max(-2)[0]                            # :431-447
+    weak_class_loss = class_criterion(syn_weak_pred, syn_target_weak)
+    weak_index = target_weak.shape[0] // 2
+    weak_class_loss = weak_class_loss + class_criterion(weak_pred, target_weak)
+    weak_freq_shift_class_loss = (class_criterion(syn_weak_freq_shift_pred, syn_target_weak)
+                                  + class_criterion(weak_freq_shift_pred[:weak_index], target_weak[:weak_index]))
+    strong_class_loss = class_criterion(syn_strong_pred, syn_target)   # :477-483
+    strong_shift_class_loss = class_criterion(syn_strong_shift_pred, syn_strong_target_shift)
+    strong_freq_shift_class_loss = class_criterion(syn_strong_freq_shift_pred, syn_target)
+    consistency_loss_strong = cc * consistency_criterion(strong_pred, strong_pred_ema)                    # :486-497
+    consistency_loss_weak = cc * consistency_criterion(weak_pred, weak_pred_ema)
+    consistency_loss_strong_shift = cc * consistency_criterion(strong_shift_pred, strong_pred_shift_ema)  # :499-512
+    consistency_loss_strong_freq_shift = cc * consistency_criterion(strong_freq_shift_pred, strong_pred_freq_shift_ema)
+    loss = strong_class_loss + weak_class_loss                         # :516-529
+    loss = loss + (consistency_loss_weak + consistency_loss_strong)
+    consistency_loss_shift = cc / 2 * (consistency_criterion(syn_strong_shift_pred, syn_strong_pred_shift)
+                                       + consistency_criterion(strong_shift_pred, strong_pred_shift))
+    loss = loss + (weak_freq_shift_class_loss + strong_shift_class_loss + strong_freq_shift_class_loss
+                   + consistency_loss_shift)
+    loss = loss + 1 / 2 * (consistency_loss_strong_shift + consistency_loss_strong_freq_shift)
+    loss.backward()
+    g = {"meta": np.array([B, T, seed], dtype=np.int64), "weight_checksum": np.array([c1, c2, c3, c4]),
+         "shift_frames": np.array(shift_list), "shift_bins": np.array(freq_shift_list),
+         "consistency_cost": np.array(cc), "loss": np.array(float(loss)),
+         "parts": np.array([float(v) for v in (strong_class_loss, weak_class_loss, consistency_loss_weak,
+                                               consistency_loss_strong, weak_freq_shift_class_loss,
+                                               strong_shift_class_loss, strong_freq_shift_class_loss,
+                                               consistency_loss_shift, consistency_loss_strong_shift,
+                                               consistency_loss_strong_freq_shift)]),
+         "strong_shift_pred": strong_shift_pred.detach().numpy(),
+         "syn_strong_freq_shift_pred": syn_strong_freq_shift_pred.detach().numpy()}
+    grads = named_grads([("crnn.", model), ("pred.", predictor)])
+    g["grad_names"] = np.array(list(grads.keys()))
+    g["grad_norms"] = np.array([np.sqrt((v.astype(np.float64) ** 2).sum()) for v in grads.values()])
+    for k, v in small_tensors(grads).items():
+        g["grad/" + k] = v
+    np.savez_compressed(os.path.join(OUT, "isp.npz"), **g)
+    print("wrote isp.npz loss", float(loss))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -445,3 +537,4 @@ if __name__ == "__main__":
     fpn_init_case()
     cnn_pred_case()
     frame_d_case()
+    isp_case()

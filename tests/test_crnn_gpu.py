@@ -329,7 +329,7 @@ def test_fused_glu_backward_matches_unfused_chain():
     assert err < 2e-5, err
 
 
-def test_isp_shift_consistency_step_matches_oracle():
+def test_isp_shift_consistency_step_matches_oracle(golden_dir):
     """-mt -ISP iteration (time / frequency rolled views, 6 student + 3 teacher forwards): loss and gradients"""
     from bsed_amd.engine import FlatSGD, SEDTrainer
     seed, B, T = 41, 4, 128
@@ -357,6 +357,21 @@ def test_isp_shift_consistency_step_matches_oracle():
                             shift_bins, consistency_cost=0.6)
     loss = SEDTrainer.isp_loss_value(out)
     assert abs(loss - float(loss_ref)) < 3e-5 * abs(loss), (loss, float(loss_ref))
+    # ... and against the fixture that the IMPORTED reference modules produced with the reference's own roll loops and loss
+    # composition (oracle/gen_golden.py::isp_case; same seeds, sizes and shifts as above)
+    g = np.load(os.path.join(golden_dir, "isp.npz"), allow_pickle=False)
+    assert [int(v) for v in g["meta"]] == [B, T, seed] and list(g["shift_frames"]) == shift_frames
+    assert abs(loss - float(g["loss"])) < 3e-5 * abs(loss), (loss, float(g["loss"]))
+    for n, ref_norm in zip(g["grad_names"], g["grad_norms"]):
+        n = str(n)
+        if ".conv" in n and n.endswith(".bias"):
+            continue            # exactly zero here, round-off in torch
+        mod, key = (crnn, n[5:].replace("cnn.cnn.", "cnn.", 1)) if n.startswith("crnn.") else (pred, n[5:])
+        got = mod.P(key).grad.detach().double()
+        assert abs(float(got.norm()) - ref_norm) <= 3e-4 * ref_norm + 1e-7, n
+        if "grad/" + n in g.files:
+            ref = torch.from_numpy(g["grad/" + n]).cuda().double()
+            assert float((got - ref).norm()) <= 3e-4 * float(ref.norm()) + 1e-7, n
     bad = _grad_check(pred, {k: p.grad for k, p in opred.named_parameters()}, tol=3e-4)
     assert not bad, bad
     bad = _grad_check(crnn, {k: p.grad for k, p in ocrnn.named_parameters()}, tol=3e-4)

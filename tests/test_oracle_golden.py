@@ -106,6 +106,42 @@ def test_mean_teacher_loss_and_ema(golden_dir):
                 np.testing.assert_allclose(sd[n].numpy(), g[key], rtol=1e-5, atol=1e-5)  # Adam normalises round-off-sized grads
 
 
+def test_isp_loss_assembly_matches_reference_golden(golden_dir):
+    """oracle.train_losses_isp against tests/golden/isp.npz, which oracle/gen_golden.py::isp_case assembled from the
+    IMPORTED reference CRNN / Predictor with the reference's own per-sample torch.roll loops and loss composition
+    (src/main_baseline.py:229-277,337-420,442-529): loss, and every parameter gradient."""
+    g = _load(golden_dir, "isp.npz")
+    B, T, seed = (int(v) for v in g["meta"])
+    rng = np.random.default_rng(seed)
+    xs = seeded.db_like_input(seed + 1, B, T); xr = seeded.db_like_input(seed + 2, B, T)
+    xe = xr + rng.normal(0, 1.0, xr.shape).astype(np.float32)
+    y = seeded.strong_targets(seed + 3, B, T // 4)
+    yw = (rng.random((B, 20)) < 0.2).astype(np.float32)
+    crnn, pred, c1, c2 = _build(0.0, seed)
+    ema_c, ema_p, c3, c4 = _build(0.0, seed + 5)
+    assert np.array_equal([c1, c2, c3, c4], g["weight_checksum"])
+    for m in (crnn, pred, ema_c, ema_p):
+        m.train()
+    tt = torch.from_numpy
+    loss = co.train_losses_isp(crnn, pred, (ema_c, ema_p), tt(xs), tt(y), tt(xr), tt(yw), tt(xe),
+                               [int(v) for v in g["shift_frames"]], [int(v) for v in g["shift_bins"]],
+                               consistency_cost=float(g["consistency_cost"]))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    grads = {"crnn." + k: p.grad for k, p in crnn.named_parameters()}
+    grads.update({"pred." + k: p.grad for k, p in pred.named_parameters()})
+    names = list(g["grad_names"])
+    norms = np.array([float(grads[n].double().norm()) for n in names])
+    # a conv bias feeding train-mode BatchNorm has an exactly-zero gradient: those rows are round-off on both sides
+    keep = np.array([not (".conv" in n and n.endswith(".bias")) for n in names])
+    np.testing.assert_allclose(norms[keep], g["grad_norms"][keep], rtol=1e-4, atol=1e-9)
+    for n in np.array(names)[keep]:
+        if "grad/" + n in g.files:
+            # per tensor, relative L2: the two assemblies add the nine passes' gradients in different orders (fp32)
+            ref = g["grad/" + n].astype(np.float64)
+            assert np.linalg.norm(grads[n].numpy() - ref) <= 1e-4 * np.linalg.norm(ref) + 1e-9, n
+
+
 def test_clip_discriminator_and_domain_loss(golden_dir):
     g = _load(golden_dir, "clipd.npz")
     B, T, seed = (int(v) for v in g["meta"])
@@ -346,3 +382,13 @@ def test_oracle_frame_discriminator_matches_reference_golden(golden_dir):
     np.testing.assert_allclose(x.grad.numpy()[:, ::7, ::5], g["dx"], atol=1e-7, rtol=1e-4)
     for k, p in m.named_parameters():
         np.testing.assert_allclose(p.grad.numpy(), g["grad/" + k], atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference only exists in the build container")
+def test_committed_fixtures_are_what_the_generator_writes():
+    """tools/check_golden.py: regenerate every fixture from the reference into a scratch directory and compare bit for bit"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_golden.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
