@@ -134,60 +134,95 @@ def test_adversarial_train_step_gradients_match_oracle():
     assert not bad, bad
 
 
-@pytest.mark.parametrize("crnn_mode,bar_crnn,bar_disc", [("bf16x3", 1.2e-2, 1.2e-2), ("fp32", 4.5e-3, 4.5e-3)])
-def test_adversarial_step_in_bench_mode_vs_fp64_oracle(crnn_mode, bar_crnn, bar_disc):
+@pytest.mark.parametrize("crnn_mode", ["bf16x3", "fp32"])
+def test_adversarial_step_in_bench_mode_vs_fp64_oracle(crnn_mode):
     """The adversarial step in the configuration ``bench.py --mode ada`` runs -- split-fp32 ("bf16x3") CRNN contractions,
     fp32-core discriminator -- at a well-conditioned size: 12 synthetic + 12 real clips of 865 frames (216 output
-    frames, the BASELINE shape), against the oracle evaluated in float64.  Relative-L2 bars only, no absolute floor.
-    The discriminator's four LeakyReLU masks make its backward sqrt-sensitive to forward rounding (a forward error eps
-    flips ~eps of the mask elements, each flip moves a gradient element by 0.8x), so its bar -- and
-    that of the CRNN tensors, which receive the reversed domain gradient -- is wider than the 2e-4 of the class-loss-only
-    step.  Measured on MI355X (largest tensor / median over tensors): 8.6e-3 / 3.8e-3 in bench mode, 3.0e-3 / 1.4e-3
-    with exact-fp32 CRNN contractions -- the ratio 2.8 is the square root of the two modes' forward-error ratio
-    (5.5e-6 vs 9.6e-7 on the logits), which is the signature of mask flips, not of a wiring error; loss to 2e-5."""
+    frames, the BASELINE shape), against the oracle evaluated in float64.  Reference: src/models/CRNN_GRL.py:16-53,
+    src/DA/cdan_frame.py:89-119, src/main_scmt_ada_weak.py:312-345,527-528.
+
+    The bar is DERIVED in the test, not asserted: the same step is also run by the stock-torch oracle in float32 (what the
+    reference itself computes), and its per-tensor relative-L2 error against the float64 oracle, e32[k], is the yardstick:
+      * exact-fp32 CRNN contractions: every tensor <= 2 x max(e32[k], median of e32 over the module's tensors)
+        (the median floor keeps a tensor on which the float32 oracle happened to flip few LeakyReLU mask elements from
+        setting an unattainable bar; 2e-4, the gradient bar of the whole suite, is the floor: the Predictor's tensors
+        receive no domain gradient and the float32 oracle is within 2e-6 of float64 on them);
+      * split-fp32 CRNN contractions (the bench's mode): the same bar times sqrt(f_hip / f_32), where f_hip and f_32 are
+        the MEASURED forward errors of the two float32 paths on the encoder output -- a forward error eps flips ~eps of
+        the discriminator's mask elements, each flip moves a gradient element by 0.8x, so gradient error grows like
+        sqrt(eps).  If this mode met only the scaled bar and not the plain 2 x e32 one, the line
+        printed below says so: that is a statement about configs[4]'s default mode, not a reason to widen anything.
+    Loss: 2e-5 relative in both modes."""
     from bsed_amd.disc import Clip_Discriminator, ConditionalDomainAdversarialLoss
     from bsed_amd.engine import FlatSGD, SEDTrainer
     from bsed_amd.models import CRNN, Predictor
     seed, B, T = 29, 12, 865
     kw = dict(co.CRNN_KWARGS); kw["dropout"] = 0.0
-    ocrnn, opred, odisc = co.CRNN(**kw), co.Predictor(**co.PREDICTOR_KWARGS), co.Clip_Discriminator()
-    seeded.load_seeded(ocrnn, seed); seeded.load_seeded(opred, seed + 1); seeded.load_seeded(odisc, seed + 2)
-    sd_c = {k: v.clone() for k, v in ocrnn.state_dict().items()}
-    sd_d = {k: v.clone() for k, v in odisc.state_dict().items()}
     xs = seeded.db_like_input(seed + 3, B, T); xr = seeded.db_like_input(seed + 4, B, T)
     y = seeded.strong_targets(seed + 5, B, T // 4)
-    for m in (ocrnn, opred, odisc):
-        m.double().train()
     it = 700
     coeff = co.grl_coeff(it)
-    loss_c, outs = co.train_losses(ocrnn, opred, torch.from_numpy(xs).double(), torch.from_numpy(y).double(),
-                                   torch.from_numpy(xr).double())
-    loss_d = co.domain_loss(odisc, outs["enc_syn"], outs["enc_real"], coeff)
-    (loss_c + loss_d).backward()
+
+    def oracle_step(dtype):
+        ocrnn, opred, odisc = co.CRNN(**kw), co.Predictor(**co.PREDICTOR_KWARGS), co.Clip_Discriminator()
+        seeded.load_seeded(ocrnn, seed); seeded.load_seeded(opred, seed + 1); seeded.load_seeded(odisc, seed + 2)
+        sd = ({k: v.clone() for k, v in ocrnn.state_dict().items()}, {k: v.clone() for k, v in opred.state_dict().items()},
+              {k: v.clone() for k, v in odisc.state_dict().items()})
+        for m in (ocrnn, opred, odisc):
+            m.to(dtype).train()
+        loss_c, outs = co.train_losses(ocrnn, opred, torch.from_numpy(xs).to(dtype), torch.from_numpy(y).to(dtype),
+                                       torch.from_numpy(xr).to(dtype))
+        loss_d = co.domain_loss(odisc, outs["enc_syn"], outs["enc_real"], coeff)
+        (loss_c + loss_d).backward()
+        grads = {}
+        for tag, omod in (("crnn", ocrnn), ("pred", opred), ("disc", odisc)):
+            for k, p in omod.named_parameters():
+                key = k.replace("cnn.cnn.", "cnn.", 1)
+                if (".conv" in key or key.startswith("conv_")) and key.endswith("bias"):
+                    continue  # exactly zero under train-mode BatchNorm (DESIGN.md D9)
+                grads[(tag, key)] = p.grad.double()
+        enc = torch.cat([outs["enc_syn"], outs["enc_real"]]).detach().double()
+        return float(loss_c + loss_d), grads, enc, sd
+
+    loss64, g64, enc64, (sd_c, sd_p, sd_d) = oracle_step(torch.float64)
+    loss32, g32, enc32, _ = oracle_step(torch.float32)
+    e32 = {k: float((g32[k] - g64[k]).norm() / g64[k].norm()) for k in g64}
+    f32 = float((enc32 - enc64).abs().max())
 
     crnn, pred, disc = CRNN(**kw), Predictor(**co.PREDICTOR_KWARGS), Clip_Discriminator()
     assert crnn.conv_mode == "bf16x3" and disc.conv_mode == "fp32"      # what bench.py --mode ada runs
     crnn.conv_mode = crnn_mode
-    crnn.load_state_dict(sd_c); pred.load_state_dict({k: v.float() for k, v in opred.state_dict().items()})
-    disc.load_state_dict(sd_d)
+    crnn.load_state_dict(sd_c); pred.load_state_dict(sd_p); disc.load_state_dict(sd_d)
+    crnn.train()
+    with torch.no_grad():
+        enc_hip = torch.cat([crnn.run_forward(torch.from_numpy(v).cuda(), save=False)[0] for v in (xs, xr)]).double().cpu()
+    f_hip = float((enc_hip - enc64).abs().max())
+    crnn.load_state_dict(sd_c)                                            # fresh running statistics for the step below
     cdan = ConditionalDomainAdversarialLoss(disc)
     cdan.iter_num = it
     tr = SEDTrainer(crnn, pred, optimizer=FlatSGD([crnn, pred], lr=0.0, momentum=0.0, weight_decay=0.0),
                     domain_loss=cdan, optimizer_d=FlatSGD([disc], lr=0.0, momentum=0.0, weight_decay=0.0))
     out = tr.train_step(torch.from_numpy(xs).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(xr).cuda())
     loss = SEDTrainer.loss_value(out)
-    assert abs(loss - float(loss_c + loss_d)) < 2e-5 * abs(loss), (loss, float(loss_c + loss_d))
-    report, bad = [], []
-    for mod, omod, bar in ((crnn, ocrnn, bar_crnn), (pred, opred, bar_crnn), (disc, odisc, bar_disc)):
-        for k, p in omod.named_parameters():
-            key = k.replace("cnn.cnn.", "cnn.", 1)
-            if (".conv" in key or key.startswith("conv_")) and key.endswith("bias"):
-                continue  # exactly zero under train-mode BatchNorm (DESIGN.md D9)
-            got, ref = mod.P(key).grad.cpu().double(), p.grad
-            err = float((got - ref).norm() / ref.norm())
-            report.append((key, err))
-            if err > bar:
-                bad.append((key, err, bar))
-    print(f"adversarial step, CRNN {crnn_mode} + fp32 discriminator, relative L2 per tensor (largest, median):",
-          sorted(report, key=lambda r: -r[1])[:6], float(np.median([r[1] for r in report])))
+    assert abs(loss - loss64) < 2e-5 * abs(loss), (loss, loss64)
+    mods = {"crnn": crnn, "pred": pred, "disc": disc}
+    med = {tag: float(np.median([v for (t_, _), v in e32.items() if t_ == tag])) for tag in mods}
+    scale = 1.0 if crnn_mode == "fp32" else max(1.0, (f_hip / f32) ** 0.5)
+    rows, bad, over_plain = [], [], 0
+    for (tag, key), ref in g64.items():
+        got = mods[tag].P(key).grad.cpu().double()
+        err = float((got - ref).norm() / ref.norm())
+        base = max(2.0 * max(e32[(tag, key)], med[tag]), 2e-4)     # never tighter than the suite-wide gradient bar
+        rows.append((key, err, e32[(tag, key)]))
+        over_plain += err > base
+        if err > scale * base:
+            bad.append((key, err, e32[(tag, key)], scale * base))
+    rows.sort(key=lambda r: -r[1] / max(r[2], 1e-12))
+    print(f"adversarial step, CRNN {crnn_mode} + fp32 discriminator vs fp64 oracle: forward error on the encoding "
+          f"{f_hip:.2e} (float32 torch oracle {f32:.2e}), bar scale {scale:.2f}; per-tensor relative L2 "
+          f"median HIP {np.median([r[1] for r in rows]):.2e} / float32 oracle {np.median([r[2] for r in rows]):.2e}; "
+          f"largest ratios: {[(k, f'{e:.1e}', f'{r:.1e}') for k, e, r in rows[:5]]}; tensors above the PLAIN 2 x e32 bar: "
+          f"{over_plain} of {len(rows)}")
     assert not bad, bad
+    if crnn_mode == "fp32":
+        assert over_plain == 0
