@@ -189,6 +189,9 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="mel transform inside the step instead of one step ahead on the feature stream")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--host-waves", action="store_true",
+                    help="diagnostic: waveform batches in pinned HOST memory, uploaded one step ahead on the trainer's copy "
+                         "stream (PCIe-inclusive rate; the headline keeps its inputs resident in HBM)")
     ap.add_argument("--dropout", type=float, default=0.5,
                     help="dropout of the CRNN (0.5 = the reference's crnn_kwargs and the BASELINE configuration; other values "
                          "are diagnostic: 0 shows what the mask hashes and the final dropout kernels cost)")
@@ -224,6 +227,7 @@ def main():
         log(f"cpu baseline done: {cpu['value']} clips/s on {cpu['cores']} threads")
 
     ngpu = torch.cuda.device_count()
+    ranks_seen = 1
     # one process per GPU; BSED_DIST_BACKEND=gloo lets several ranks share one card for rehearsals of the N>1 path
     backend = os.environ.get("BSED_DIST_BACKEND", "nccl")
     dev_index = local_rank % max(ngpu, 1) if backend != "nccl" else local_rank
@@ -245,6 +249,7 @@ def main():
             probe = torch.ones(1, device=dev)
             torch.distributed.all_reduce(probe)
             torch.cuda.synchronize()
+            ranks_seen = int(probe.item())       # evidence in the JSON line that the backend summed over N ranks
         finally:
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
@@ -326,6 +331,15 @@ def main():
                 return tr.train_step(b0[0], b0[1], b0[2], b0[3], from_wave=True,
                                      next_waves=None if args.no_pipeline else (b1[0], b1[2]))
 
+    if args.host_waves and tr is not None:
+        # diagnostic: the caller's batches live in PINNED HOST memory; SEDTrainer uploads the next step's waveforms on
+        # its copy stream at the start of every step (PCIe-inclusive rate: never the headline `value`)
+        if args.mode == "crnn":
+            batches = [(w_.cpu().pin_memory(), y_) for w_, y_ in batches]
+        else:
+            batches = [(b[0].cpu().pin_memory(), b[1], b[2].cpu().pin_memory(), b[3]) for b in batches]
+    if tr is not None:
+        tr.arena.timing = world > 1 or tr.arena.exchange_single_rank
     log(f"data ready: B={B} n={n} T={T} Tp={Tp}")
     use_timer = not args.no_kernel_timer and rank == 0
     # The warm-up runs with a throw-away kernel timer: the first few hundred HIP events of a process make the runtime
@@ -365,6 +379,36 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax)
+    dp = None
+    if tr is not None and (world > 1 or tr.arena.exchange_single_rank):
+        # what the gradient exchange cost: (a) how long the step's stream actually WAITED in GradArena.finish() for the
+        # early + tail all-reduces (events around the waits, inside the timed region: the exposed part of the exchange);
+        # (b) the two all-reduces alone, back to back on an otherwise idle GPU, after the timed region (every rank takes
+        # part: collective).  All ranks run this block.
+        ar = tr.arena
+        waits = [a.elapsed_time(b) for a, b in ar.wait_events]
+        alone = {}
+        for nm, buf in (("early", ar.early), ("tail", ar.tail)):
+            if buf.numel() == 0:
+                continue
+            scratch = torch.zeros_like(buf)
+            for _ in range(3):
+                torch.distributed.all_reduce(scratch)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                torch.distributed.all_reduce(scratch)
+            e1.record()
+            torch.cuda.synchronize()
+            alone[nm] = e0.elapsed_time(e1) / 20
+        dp = {"ranks_seen": ranks_seen, "backend": backend, "allreduce_mb": round(ar.flat.numel() * 4 / 1e6, 3),
+              "early_mb": round(ar.early.numel() * 4 / 1e6, 3), "tail_kb": round(ar.tail.numel() * 4 / 1e3, 2),
+              "exchanges_per_step": round(ar.exchanges / max(1, args.steps + args.warmup), 2),
+              "finish_wait_ms_per_step": round(float(np.mean(waits)), 4) if waits else None,
+              "finish_wait_ms_max": round(float(np.max(waits)), 4) if waits else None,
+              "allreduce_early_ms_alone": round(alone.get("early", 0.0), 4),
+              "allreduce_tail_ms_alone": round(alone.get("tail", 0.0), 4)}
     if args.mode == "cnn":
         loss = float(out[1].mean())      # mean weak probability: a finite-output check, not a loss
     else:
@@ -476,7 +520,11 @@ def main():
                    "input_pipeline": "none" if (args.mode == "cnn" or args.no_pipeline) else
                    "2 alternating resident batches; each step transforms the next step's waveforms (feature stream)"},
         "roofline": roofline, "cpu_baseline": cpu, "final_loss": round(loss, 5),
+        "ranks_seen": ranks_seen, "data_parallel": dp,
     }
+    if args.host_waves:
+        line["config"]["input_pipeline"] = ("pinned HOST waveforms, uploaded one step ahead on the trainer's copy stream "
+                                            "(PCIe-inclusive diagnostic, not the headline)")
     line.update(extra_fields)
     print(json.dumps(line))
     if torch.distributed.is_initialized():

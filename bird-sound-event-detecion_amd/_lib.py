@@ -12,8 +12,25 @@ import re
 # beyond that two streams share a queue and their kernels serialise, which takes the overlap back -- measured on one
 # MI355X box, same process otherwise: 13.28 ms per step; 13.63 once an RCCL communicator exists; 13.31 with 8 queues
 # (DESIGN.md section 7).  Read by the runtime when it initialises, so it is set at import, before the first HIP call;
-# an explicit setting in the environment wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# an explicit setting in the environment wins; importing after the runtime is up only warns (import order is not an API:
+# launch scripts and the profiling tools under tools/ export the variable themselves).
+def _hw_queue_default():
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        return
+    import sys
+    t = sys.modules.get("torch")
+    if t is not None and getattr(t, "cuda", None) is not None and t.cuda.is_initialized():
+        # too late: the runtime has read its configuration.  Say so instead of silently running on 4 queues.
+        import warnings
+        warnings.warn("bsed_amd was imported after the HIP runtime was initialised and GPU_MAX_HW_QUEUES is not set: the "
+                      "train step's streams and RCCL's will share the default 4 hardware queues (2.5-3.4 % slower steps "
+                      "once an RCCL communicator exists, DESIGN.md section 7).  Export GPU_MAX_HW_QUEUES=8 in the "
+                      "launch environment, or import bsed_amd before the first torch.cuda call.", RuntimeWarning)
+        return
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
+
+_hw_queue_default()
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSED_LIB_PATH") or os.path.join(_HERE, "libbsed.so")  # override: A/B experiment builds

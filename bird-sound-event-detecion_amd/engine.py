@@ -225,6 +225,7 @@ class SEDTrainer:
         self.seed = seed
         self.pg = process_group
         self._prefetched, self._feat_stream = {}, None   # train_step(..., next_waves=...): features one step ahead
+        self._uploaded, self._copy_stream, self._slots = {}, None, {}   # host waveforms: uploads one step ahead
         # mean teacher: the EMA pair's forward on its own stream beside the student's passes (BSED_TEACHER_OVERLAP=0: inline)
         self.teacher_overlap = os.environ.get("BSED_TEACHER_OVERLAP", "1") != "0"
         self._teacher_stream = None
@@ -261,6 +262,48 @@ class SEDTrainer:
             if getattr(m, "nbt", None) is not None:
                 parallel.broadcast_flat([m.nbt], src, self.pg)
 
+    def _device_wave(self, wav):
+        """A waveform batch as a device tensor.  Device tensors pass through.  A HOST tensor (pinned memory, if the
+        upload is to overlap anything) that a previous ``train_step(next_waves=...)`` announced was uploaded on the copy
+        stream one step ago: the current stream waits for that copy's event.  An unannounced host tensor is uploaded
+        here, on the current stream, in front of its consumer (blocking upload: the PCIe time is then inside the step)."""
+        if wav.is_cuda:
+            return wav
+        up = self._uploaded.pop(id(wav), None)
+        if up is not None and up[0] is wav:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(up[2])
+            up[1].record_stream(cur)
+            return up[1]
+        return wav.to(self.crnn.flat.device, non_blocking=True)
+
+    def _upload_ahead(self, waves, step):
+        """Start the host -> device copies of the NEXT step's waveforms on the copy stream (the copy engine works beside
+        this step's kernels: 226 MB per 256 clips = ~4 ms of PCIe at 57 GB/s).  Two device slots per
+        shape alternate: the slot refilled now held the batch of two steps ago, whose transform was enqueued on the feature
+        stream during the step before last."""
+        host = [w for w in waves if w is not None and not w.is_cuda]
+        if not host:
+            return
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream()
+        dev = self.crnn.flat.device
+        cs = self._copy_stream
+        cs.wait_stream(torch.cuda.current_stream())
+        if self._feat_stream is not None:
+            cs.wait_stream(self._feat_stream)
+        with torch.cuda.stream(cs):
+            for k, w in enumerate(host):
+                key = (k, tuple(w.shape), w.dtype)
+                slots = self._slots.setdefault(key, [None, None])
+                i = step % 2
+                if slots[i] is None:
+                    slots[i] = torch.empty(w.shape, dtype=w.dtype, device=dev)
+                slots[i].copy_(w, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._uploaded[id(w)] = (w, slots[i], ev, step)
+
     def _features(self, wav, noisy=False, step=None):
         pre = self._prefetched.pop(id(wav), None)
         if pre is not None and pre[0] is wav and pre[1] == (noisy, self.global_step):
@@ -270,15 +313,25 @@ class SEDTrainer:
             for t in (pre[2] if isinstance(pre[2], tuple) else (pre[2],)):
                 t.record_stream(torch.cuda.current_stream())
             return pre[2]
-        T = self.frontend.num_frames(wav.shape[1])
-        return self.frontend.transform(wav, max_frames=T, noisy=noisy,
+        dwav = self._device_wave(wav)
+        T = self.frontend.num_frames(dwav.shape[1])
+        return self.frontend.transform(dwav, max_frames=T, noisy=noisy,
                                        seed=parallel.rank_seed(self.seed, self.global_step if step is None else step, self.rank))
+
+    def _drop_stale_inputs(self):
+        """Entries announced for this step or an earlier one that nobody consumed (the caller passed other tensors: last
+        batch of an epoch, a skipped batch, an exception between steps) would otherwise pin a waveform batch, its
+        feature tensors and an event forever."""
+        for table, tag in ((self._prefetched, lambda v: v[1][1]), (self._uploaded, lambda v: v[3])):
+            for k in [k for k, v in table.items() if tag(v) <= self.global_step]:
+                del table[k]
 
     def _prefetch_features(self, waves):
         """Enqueue the NEXT step's waveform -> dB-mel transforms on the feature stream.  Called from the CRNN's
         recurrence hook: the two GRU layers are latency-bound and occupy half the chip (one workgroup per 4 batch rows),
         the mel kernels run beside them.  waves: [(wav, noisy), ...]; the caller must leave the waveform tensors
-        untouched until the next train_step has consumed them."""
+        untouched until the next train_step has consumed them.  Host waveforms were put on the copy stream at the start
+        of this step (_upload_ahead); the feature stream waits for their events."""
         if self._feat_stream is None:
             self._feat_stream = torch.cuda.Stream()
         main = torch.cuda.current_stream()
@@ -333,7 +386,9 @@ class SEDTrainer:
         next_waves (with from_wave): ``(next_syn_wav, next_real_wav or None)`` -- the waveforms the NEXT call will be
         given.  Their mel transforms are enqueued on a second stream while this step's recurrences run (a two-deep
         input pipeline: every step still transforms one batch, one step ahead); the next call must pass the same
-        tensor objects, unmodified.  Results are bit-identical to the unpipelined step.
+        tensor objects, unmodified.  Results are bit-identical to the unpipelined step.  The waveforms may be HOST
+        tensors (pinned): the next step's are then uploaded on a copy stream at the start of this step, beside its
+        kernels, into two alternating device slots (an unannounced host batch is uploaded in front of its transform).
         Returns a dict of DEVICE tensors with the per-term loss sums (no host sync)."""
         crnn, pred = self.crnn, self.predictor
         mt = self.ema_crnn is not None and real_x is not None
@@ -353,6 +408,9 @@ class SEDTrainer:
                     real_x, real_x_ema = self._features(real_x, noisy=True)
                 else:
                     real_x = self._features(real_x)
+            self._drop_stale_inputs()
+            if next_waves is not None:
+                self._upload_ahead(next_waves, self.global_step + 1)     # host tensors only; device tensors: no-op
         step_seed = parallel.rank_seed(self.seed, self.global_step, self.rank)
         crnn.train(); pred.train()
         self.arena.zero_()

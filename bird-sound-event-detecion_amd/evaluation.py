@@ -49,6 +49,8 @@ def decode_regions_gpu(mask, scale, max_len_seconds):
     two HIP launches (count, write at the exclusive prefix of the counts)."""
     mask = mask.contiguous()
     B, T, C = mask.shape
+    if B * C == 0 or T == 0:                            # an empty batch decodes to an empty event list
+        return (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 2), np.int32), np.zeros((0, 2), np.float64))
     counts = torch.empty(B * C, device=mask.device, dtype=torch.int32)
     L.call("bsed_decode_count", L.ptr(mask), L.c_int(B), L.c_int(T), L.c_int(C), L.ptr(counts, torch.int32), L.stream())
     csum = torch.cumsum(counts, 0, dtype=torch.int32)
@@ -75,21 +77,51 @@ def _decoder_labels(decoder):
     return None
 
 
+# reference src/data/config.py:62-63: cfg.median_window = [max(int(s * out_nb_frames_1s), 1) for s in median_window_s_classwise]
+MEDIAN_WINDOW_S_CLASSWISE = [0.45, 0.45, 0.45, 0.45, 0.45, 2.7, 2.7, 2.7, 0.45, 2.7]
+
+
+def classwise_median_windows(sr=32000, hop_size=255, pooling_time_ratio=4, seconds=MEDIAN_WINDOW_S_CLASSWISE):
+    out_nb_frames_1s = sr / hop_size / pooling_time_ratio
+    return [max(int(s * out_nb_frames_1s), 1) for s in seconds]
+
+
+def binarize_median_classwise_gpu(pred_strong, threshold, windows):
+    """``learned_post`` of the reference (src/evaluation_measures.py:192-197): class k gets its own median window
+    ``windows[k]``; like the reference's ``np.hstack`` over ``range(len(cfg.median_window))``, classes beyond the list
+    are dropped (no events).  One HIP launch per DISTINCT window, columns merged on the GPU."""
+    B, T, C = pred_strong.shape
+    out = torch.zeros_like(pred_strong)
+    for w in sorted(set(windows[:C])):
+        cols = torch.tensor([k for k, wk in enumerate(windows[:C]) if wk == w], device=pred_strong.device)
+        out[:, :, cols] = binarize_median_gpu(pred_strong, threshold, w)[:, :, cols]
+    return out
+
+
 def get_predictions(model, dataloader, decoder, pooling_time_ratio=1, thresholds=(0.5,), median_window=1,
                     save_predictions=None, del_model=False, learned_post=False, predictor=None, fpn=False,
-                    saved_feature_dir=None, sr=32000, hop_size=255, max_len_seconds=10.0):
+                    saved_feature_dir=None, sr=32000, hop_size=255, max_len_seconds=10.0, classwise_median_window=None,
+                    require_annotations=False):
     """Same call signature and return value as the reference: ``(predictions, groundtruth_df, duration_df)``.
     ``dataloader`` yields ``(((input, ema_input), target), paths)`` batches.  predictions: one DataFrame (or a list,
     one per threshold) with columns event_label / onset / offset / filename (seconds); groundtruth_df: the
     ``annotation/<name>.txt`` files of the clips concatenated with a ``filename`` column; duration_df: filename /
-    duration (10, as the reference hard-codes it)."""
+    duration (10, as the reference hard-codes it).
+    learned_post: class-wise median windows (``classwise_median_window``, default the reference's ``cfg.median_window``
+    list for this sr / hop / pooling).  predictor=None: ``model`` returns ``(strong, weak)`` itself and is called as
+    ``model(x, inference=True)`` when ``fpn`` (reference :180-181; its ``seg_index`` form belongs to a model class that is
+    not on the path).  Clips without an ``annotation/<name>.txt`` (unlabelled / pseudo-labelled sets) are left out of
+    groundtruth_df -- None when no clip has one -- unless ``require_annotations`` (the reference's behaviour: it raises)."""
     import pandas as pd
-    if predictor is None:
-        raise NotImplementedError("bsed_amd.get_predictions needs the CRNN + Predictor pair (predictor=...)")
-    if learned_post:
-        raise NotImplementedError("learned_post (class-wise median windows) is not on the hot path")
-    was_training = (model.training, predictor.training)
-    model.eval(); predictor.eval()
+    if predictor is None and not fpn:
+        raise NotImplementedError("get_predictions(predictor=None, fpn=False) is the reference's seg_index call of a model "
+                                  "class outside the hot path; pass predictor=... or a self-contained model with fpn=True")
+    if learned_post and classwise_median_window is None:
+        classwise_median_window = classwise_median_windows(sr, hop_size, pooling_time_ratio)
+    was_training = (model.training, predictor.training if predictor is not None else False)
+    model.eval()
+    if predictor is not None:
+        predictor.eval()
     labels = _decoder_labels(decoder)
     scale = pooling_time_ratio / (sr / hop_size)
     frames = {t: [] for t in thresholds}
@@ -99,12 +131,16 @@ def get_predictions(model, dataloader, decoder, pooling_time_ratio=1, thresholds
         folders = [os.path.join(os.path.dirname(os.path.dirname(p)), "annotation") for p in paths]
         with torch.no_grad():
             x = torch.as_tensor(input_data).float().cuda()
-            encoded_x, feature_out = model(x)
-            pred_strong, _ = predictor(encoded_x, inference=fpn)
-        if saved_feature_dir is not None:
+            if predictor is not None:
+                encoded_x, feature_out = model(x)
+                pred_strong, _ = predictor(encoded_x, inference=fpn)
+            else:
+                pred_strong, feature_out = model(x, inference=True)[0], None
+        if saved_feature_dir is not None and feature_out is not None:
             np.save(os.path.join(saved_feature_dir, f"{i}"), feature_out.cpu().numpy())
         for t in thresholds:
-            mask = binarize_median_gpu(pred_strong, t, median_window)
+            mask = (binarize_median_classwise_gpu(pred_strong, t, list(classwise_median_window)) if learned_post
+                    else binarize_median_gpu(pred_strong, t, median_window))
             if labels is not None:
                 ev_clip, ev_class, _, ev_sec = decode_regions_gpu(mask, scale, max_len_seconds)
                 frames[t].append(pd.DataFrame({"event_label": np.asarray(labels, dtype=object)[ev_class],
@@ -120,7 +156,9 @@ def get_predictions(model, dataloader, decoder, pooling_time_ratio=1, thresholds
                 frames[t].append(pd.DataFrame(rows, columns=["event_label", "onset", "offset", "filename"]))
         filename_list += names
         annotation_folder_list += folders
-    model.train(was_training[0]); predictor.train(was_training[1])
+    model.train(was_training[0])
+    if predictor is not None:
+        predictor.train(was_training[1])
     cols = ["event_label", "onset", "offset", "filename"]
     dfs = [pd.concat(frames[t], ignore_index=True)[cols] if frames[t] else pd.DataFrame(columns=cols)
            for t in thresholds]
@@ -133,19 +171,22 @@ def get_predictions(model, dataloader, decoder, pooling_time_ratio=1, thresholds
     duration_df = pd.DataFrame(list(seen.keys()), columns=["filename"])
     duration_df["duration"] = 10
     groundtruth_df = None
-    gts = []
+    gts, n_found = [], 0
     for name, folder in seen.items():
         path = os.path.join(folder, name + ".txt")
         if not os.path.exists(path):
-            raise FileNotFoundError(f"get_predictions: annotation file {path} is missing (the reference reads "
-                                    "annotation/<name>.txt next to wav/<name>.npy)")
+            if require_annotations:
+                raise FileNotFoundError(f"get_predictions: annotation file {path} is missing (the reference reads "
+                                        "annotation/<name>.txt next to wav/<name>.npy)")
+            continue                                    # unlabelled clip: predictions only
+        n_found += 1
         df = pd.read_csv(path, sep="\t")
         df["filename"] = name
         if len(df):
             gts.append(df)
     if gts:
         groundtruth_df = pd.concat(gts, ignore_index=True)
-    elif seen:
+    elif n_found:
         groundtruth_df = pd.DataFrame(columns=["onset", "offset", "event_label", "filename"])
 
     if save_predictions is not None:

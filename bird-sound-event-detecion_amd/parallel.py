@@ -2,6 +2,8 @@
 ROCm, "gloo" in the CPU tests).  The reference has no distributed code: this is the MI355X-side design of
 SURVEY.md section 8(e) -- shard clips by rank, keep BatchNorm statistics per rank, exchange ONE flat gradient
 buffer per module per step, fold 1/world into the optimizer."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -31,9 +33,15 @@ class GradArena:
     Sums only: the 1/world factor is folded into the optimizer kernel.  With world size 1 both are no-ops (and the
     arena still makes zero_grad one memset).  SURVEY.md section 8(e); the reference has no distributed code."""
 
-    def __init__(self, modules, tail_floats=0, group=None):
+    def __init__(self, modules, tail_floats=0, group=None, exchange_single_rank=None):
+        """exchange_single_rank: run the two all-reduces even in a group of ONE rank (identity on the data, but they
+        execute on the backend's stream with the real dependencies) -- the one way a single-GPU box can put
+        begin_early / finish through RCCL (tests/test_dp_gpu.py); default from BSED_DP_SINGLE_RANK_EXCHANGE."""
         self.modules = [m for m in modules if m is not None]
         self.group = group
+        if exchange_single_rank is None:
+            exchange_single_rank = os.environ.get("BSED_DP_SINGLE_RANK_EXCHANGE", "0") == "1"
+        self.exchange_single_rank = bool(exchange_single_rank)
         sizes = [m.flat_grad.numel() for m in self.modules]
         dev = self.modules[0].flat_grad.device
         self.flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
@@ -51,6 +59,9 @@ class GradArena:
         self.tail = self.flat[:self.tail_floats]
         self.early = self.flat[self.tail_floats:]
         self._work = None
+        self.exchanges = 0          # all-reduces issued so far (evidence for the tests / the bench line)
+        self.timing = False         # bench.py: record events around the waits of finish()
+        self.wait_events = []       # [(before, after)] pairs on the stream that waited
 
     @property
     def world(self):
@@ -58,26 +69,52 @@ class GradArena:
             return 1
         return dist.get_world_size(self.group)
 
+    def _exchanging(self):
+        if not dist.is_available() or not dist.is_initialized():
+            return False
+        return dist.get_world_size(self.group) > 1 or self.exchange_single_rank
+
+    def _check_bound(self):
+        """A later GradArena (a second SEDTrainer over the same modules, a trainer rebuilt after resume) rebinds the
+        modules' flat_grad to ITS storage: this arena would then clear and all-reduce dead storage while the gradients
+        accumulate elsewhere.  Fail loudly instead (two pointer compares per module, host side)."""
+        for m in self.modules:
+            lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.flat.numel()
+            if not (lo <= m.flat_grad.data_ptr() < hi):
+                raise RuntimeError(f"{type(m).__name__}.flat_grad no longer lives in this GradArena (rebound by another "
+                                   "arena or trainer): this arena is stale")
+
     def zero_(self):
+        self._check_bound()
         self.flat.zero_()
 
     def begin_early(self):
-        if self.world == 1 or self._work is not None:
+        if not self._exchanging() or self._work is not None:
             return
+        self._check_bound()
         # async_op: the collective runs on the backend's own stream after everything enqueued so far on the current
         # stream, concurrently with what the caller enqueues next (RCCL); gloo stages through the host instead
         self._work = dist.all_reduce(self.early, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.exchanges += 1
 
     def finish(self):
-        if self.world == 1:
+        if not self._exchanging():
             return
         if self._work is None:
             self.begin_early()
         works = [self._work]
         if self.tail_floats:
             works.append(dist.all_reduce(self.tail, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.exchanges += 1
+        ev = None
+        if self.timing and self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in works:
             w.wait()
+        if ev is not None:
+            ev[1].record()
+            self.wait_events.append(ev)
         self._work = None
 
 

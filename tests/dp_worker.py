@@ -3,7 +3,8 @@
     python tests/dp_worker.py <rank> <world> <port> <outdir> [backend]
 
 Both ranks share cuda:0 (backend "gloo": the collective goes through the host, which is what lets several ranks sit on
-one card).  Each rank takes clips rank::world of a seeded batch, runs one plain step and one mean-teacher step through
+one card).  With world = 1 and backend "nccl" the single rank is made to exchange anyway (GradArena.exchange_single_rank):
+begin_early / finish then execute on RCCL's stream -- all of the N > 1 path that one GPU can run.  Each rank takes clips rank::world of a seeded batch, runs one plain step and one mean-teacher step through
 SEDTrainer (dropout 0.5, per-rank seeds) with lr = 0 optimizers, and saves the all-reduced gradient arena."""
 import os
 import sys
@@ -36,19 +37,21 @@ def batch(B=8, T=128):
     return x, y, xr, xe, yw
 
 
-def run_steps(rank, world, group_ready):
+def run_steps(rank, world, group_ready, force_exchange=False):
     """-> dict of CPU tensors: summed gradient arenas of the two steps (+ losses)"""
     import torch
     from bsed_amd.engine import FlatSGD, SEDTrainer
     x, y, xr, xe, yw = batch()
     sh = slice(rank, None, world)
-    out = {}
+    out = {"exchanges": 0}
     # plain step
     crnn, pred = build(7)
     tr = SEDTrainer(crnn, pred, optimizer=FlatSGD([crnn, pred], lr=0.0, momentum=0.0, weight_decay=0.0), seed=11)
     if not group_ready:
         tr.rank, tr.world = rank, 1          # single-process emulation of one rank: same seeds, no exchange
+    tr.arena.exchange_single_rank = force_exchange
     res = tr.train_step(x[sh].contiguous(), y[sh].contiguous())
+    out["exchanges"] += tr.arena.exchanges
     out["plain"] = tr.arena.flat.detach().cpu().clone()
     out["plain_loss"] = torch.tensor(SEDTrainer.loss_value(res))
     # mean-teacher step (two backward passes; the exchange starts inside the second)
@@ -57,7 +60,9 @@ def run_steps(rank, world, group_ready):
     tr = SEDTrainer(crnn, pred, ema_c, ema_p, optimizer=FlatSGD([crnn, pred], lr=0.0, momentum=0.0, weight_decay=0.0), seed=11)
     if not group_ready:
         tr.rank, tr.world = rank, 1
+    tr.arena.exchange_single_rank = force_exchange
     tr.train_step(x[sh].contiguous(), y[sh].contiguous(), xr[sh].contiguous(), yw[sh].contiguous(), xe[sh].contiguous())
+    out["exchanges"] += tr.arena.exchanges
     out["mt"] = tr.arena.flat.detach().cpu().clone()
     out["tail_floats"] = torch.tensor(tr.arena.tail_floats)
     return out
@@ -71,7 +76,10 @@ def main():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group(backend, rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     from bsed_amd.engine import SEDTrainer
     # broadcast_parameters: rank 1 starts from different weights and must end up with rank 0's
     crnn, pred = build(7 if rank == 0 else 8)
@@ -80,7 +88,9 @@ def main():
     tr.broadcast_parameters()
     ref_c, _ = build(7)
     assert torch.equal(crnn.flat, ref_c.flat) and torch.equal(crnn.flat_buf, ref_c.flat_buf)
-    out = run_steps(rank, world, group_ready=True)
+    # a group of ONE rank on RCCL: the early / tail all-reduces are identities, but they run on RCCL's stream with the
+    # step's real dependencies (begin_early from inside the last backward pass, finish before the optimizer)
+    out = run_steps(rank, world, group_ready=True, force_exchange=(world == 1))
     torch.save(out, os.path.join(outdir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

@@ -57,3 +57,26 @@ def test_two_rank_gradient_exchange_matches_per_rank_gradients(tmp_path):
     assert 0 < tail < got[0]["plain"].numel() // 50              # the late segment is the first two blocks: tiny
     for r in range(2):
         assert abs(float(got[r]["plain_loss"]) - float(mine[r]["plain_loss"])) == 0.0
+
+
+def test_single_rank_rccl_group_runs_the_exchange_path(tmp_path):
+    """SEDTrainer under a 1-rank "nccl" (= RCCL) process group with the exchange forced on: begin_early is issued from
+    inside the last backward pass and finish waits for early + tail before the optimizer, on RCCL's own stream.  The
+    all-reduce of one rank is the identity, so the arena must equal, bit for bit, the one a group-less process computes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dp_worker
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), "0", "1", _free_port(), str(tmp_path),
+                          "nccl"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        out, _ = p.communicate(timeout=420)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        raise
+    assert p.returncode == 0, out
+    got = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    mine = dp_worker.run_steps(0, 1, group_ready=False)
+    assert int(got["exchanges"]) == 4 and int(mine["exchanges"]) == 0     # early + tail, plain and mean-teacher step
+    for key in ("plain", "mt"):
+        assert float(mine[key].abs().max()) > 0
+        assert torch.equal(got[key], mine[key]), (key, float((got[key] - mine[key]).abs().max()))

@@ -83,3 +83,65 @@ def test_decode_regions_gpu_matches_decode_strong_bit_exactly():
         assert got == want, (B, T, C)
         sec = np.clip(np.asarray([[w[2], w[3]] for w in want], dtype=np.float64).reshape(-1, 2) * scale, 0, 10.0)
         assert ev_sec.dtype == np.float64 and np.array_equal(ev_sec, sec)
+
+
+def test_get_predictions_learned_post_unlabelled_clips_and_self_contained_model(tmp_path):
+    """the reference's remaining call forms (src/evaluation_measures.py:163-199,226-247): class-wise median windows
+    (learned_post, restated with scipy per class like the reference's loop), clips without an annotation file
+    (unlabelled / pseudo-labelled sets), predictor=None with a model that returns (strong, weak) itself, empty decode"""
+    import scipy.ndimage
+    from bsed_amd.evaluation import (classwise_median_windows, decode_regions_gpu, get_predictions)
+    from bsed_amd.labels import BIRD_LIST, ManyHotEncoder
+    from bsed_amd.models import CRNN, Predictor
+    seed, B, T = 33, 3, 256
+    ocrnn, opred = co.CRNN(**co.CRNN_KWARGS), co.Predictor(**co.PREDICTOR_KWARGS)
+    seeded.load_seeded(ocrnn, seed); seeded.load_seeded(opred, seed + 1)
+    with torch.no_grad():
+        opred.dense.bias += 1.0
+    crnn, pred = CRNN(**co.CRNN_KWARGS), Predictor(**co.PREDICTOR_KWARGS)
+    crnn.load_state_dict(ocrnn.state_dict()); pred.load_state_dict(opred.state_dict())
+    x = seeded.db_like_input(seed + 2, B, T)
+    root = tmp_path / "d"
+    (root / "wav").mkdir(parents=True); (root / "annotation").mkdir()
+    with open(root / "annotation" / "clip1.txt", "w") as f:          # only ONE of the three clips is labelled
+        f.write("onset\toffset\tevent_label\n2.0\t3.0\tEATO\n")
+    loader = [(((torch.from_numpy(x), torch.from_numpy(x)), None), [str(root / "wav" / f"clip{i}.npy") for i in range(B)])]
+    enc = ManyHotEncoder(BIRD_LIST, n_frames=T // 4)
+    windows = classwise_median_windows(32000, 255, 4)
+    assert windows == [14, 14, 14, 14, 14, 84, 84, 84, 14, 84]       # cfg.median_window of the reference at 32 kHz / 255 / 4
+    df, gt_df, dur_df = get_predictions(crnn, loader, enc.decode_strong, pooling_time_ratio=4, thresholds=[0.5],
+                                        predictor=pred, learned_post=True)
+    assert list(gt_df.filename) == ["clip1"] and len(dur_df) == 3
+    with pytest.raises(FileNotFoundError):
+        get_predictions(crnn, loader, enc.decode_strong, pooling_time_ratio=4, predictor=pred, require_annotations=True)
+    ocrnn.eval(); opred.eval()
+    with torch.no_grad():
+        strong, _ = opred(ocrnn(torch.from_numpy(x))[0])
+    ref = []
+    scale = 4 / (32000 / 255)
+    for j in range(B):
+        binar = (strong[j].numpy() > 0.5).astype(np.float64)
+        cols = [scipy.ndimage.median_filter(binar[:, k:k + 1], (windows[k], 1)) for k in range(len(windows))]
+        m = np.hstack(cols)                                         # 10 columns: the classes beyond the list drop out
+        for k in range(m.shape[1]):
+            for on, off in lo.find_contiguous_regions(m[:, k]):
+                ref.append((BIRD_LIST[k], round(float(np.clip(on * scale, 0, 10)), 6),
+                            round(float(np.clip(off * scale, 0, 10)), 6), f"clip{j}"))
+    got = [(r.event_label, round(r.onset, 6), round(r.offset, 6), r.filename) for r in df.itertuples()]
+    assert len(ref) > 0 and got == ref
+
+    class Whole(torch.nn.Module):                                     # a model that carries its own head (reference :180-181)
+        def forward(self, inp, inference=False):
+            return pred(crnn(inp)[0], inference=inference)
+    whole = Whole()
+    df_a, gt_a, _ = get_predictions(whole, loader, enc.decode_strong, pooling_time_ratio=4, median_window=5, fpn=True)
+    df_b, _, _ = get_predictions(crnn, loader, enc.decode_strong, pooling_time_ratio=4, median_window=5, fpn=True,
+                                 predictor=pred)
+    assert len(df_b) > 0 and df_a.equals(df_b)
+    with pytest.raises(NotImplementedError):
+        get_predictions(whole, loader, enc.decode_strong)
+    # no clip with an annotation at all -> groundtruth_df None; an empty batch decodes to an empty list
+    (root / "annotation" / "clip1.txt").unlink()
+    assert get_predictions(crnn, loader, enc.decode_strong, pooling_time_ratio=4, predictor=pred)[1] is None
+    out = decode_regions_gpu(torch.zeros((0, 64, 20), device="cuda"), scale, 10.0)
+    assert all(len(a) == 0 for a in out)

@@ -124,7 +124,10 @@ def test_feature_pipeline_gives_the_same_steps(mt):
         ys = torch.from_numpy(seeded.strong_targets(30 + k, nb, Tp)).cuda()
         data.append((ws, ys, wr if mt else None, ys.max(1)[0].contiguous() if mt else None))
     runs = []
-    for pipelined in (False, True):
+    host = [tuple(t.cpu().pin_memory() if (t is not None and j in (0, 2)) else t for j, t in enumerate(d)) for d in data]
+    for pipelined in (False, True, "host"):
+        # "host": the caller hands PINNED HOST waveforms; the trainer uploads the next step's on its copy stream at the
+        # start of each step (two alternating device slots) and transforms them on the feature stream as before
         crnn, pred = _models(0.5)
         extra = {}
         if mt:
@@ -135,17 +138,26 @@ def test_feature_pipeline_gives_the_same_steps(mt):
         tr = SEDTrainer(crnn, pred, optimizer=FlatAdam([crnn, pred], lr=1e-3), frontend=fe, seed=11, **extra)
         tr.teacher_overlap = pipelined     # the EMA teacher's forward on its own stream beside the student's passes
         trace = []
+        src = host if pipelined == "host" else data
         for i in range(3):
-            ws, ys, wr, yw = data[i % 2]
-            nxt = data[(i + 1) % 2]
+            ws, ys, wr, yw = src[i % 2]
+            nxt = src[(i + 1) % 2]
             out = tr.train_step(ws, ys, wr, yw, from_wave=True, next_waves=(nxt[0], nxt[2]) if pipelined else None)
             trace.append((SEDTrainer.loss_value(out), crnn.flat.clone(), pred.flat.clone()))
         if pipelined:
             assert len(tr._prefetched) == (2 if mt else 1)    # the fourth step's features are waiting
+            assert len(tr._uploaded) == 0                      # every announced upload was consumed by its transform
+        if pipelined == "host":
+            assert tr._copy_stream is not None and len(tr._slots) == (2 if mt else 1)
+            # a step whose inputs were never announced (other tensors): the stale entries go, nothing leaks
+            other = tuple(t.clone() if t is not None else None for t in data[0])
+            tr.train_step(other[0], other[1], other[2], other[3], from_wave=True)
+            assert len(tr._prefetched) == 0 and len(tr._uploaded) == 0
         runs.append(trace)
-    for (la, ca, pa), (lb, cb, pb) in zip(*runs):
-        assert la == lb
-        assert torch.equal(ca, cb) and torch.equal(pa, pb)
+    for other_run in runs[1:]:
+        for (la, ca, pa), (lb, cb, pb) in zip(runs[0], other_run):
+            assert la == lb
+            assert torch.equal(ca, cb) and torch.equal(pa, pb)
 
 
 def test_train_step_is_bitwise_repeatable_at_full_size():

@@ -99,3 +99,42 @@ def test_single_process_helpers_are_noops():
     assert parallel.all_reduce_flat([g]) == [] and torch.equal(g, torch.ones(5))
     parallel.broadcast_flat([g])
     assert parallel.max_over_ranks(3.5, torch.device("cpu")) == 3.5
+
+
+def test_stale_arena_fails_loudly():
+    """a second GradArena over the same module rebinds its gradients: the first one must refuse to work on dead storage"""
+    from bsed_amd import parallel
+    m = _toy_module([("a.weight", (2, 2)), ("b.weight", (3,))])
+    first = parallel.GradArena([m], tail_floats=4)
+    first.zero_()
+    second = parallel.GradArena([m], tail_floats=4)
+    second.zero_()
+    with pytest.raises(RuntimeError, match="stale"):
+        first.zero_()
+
+
+def _single_rank_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from bsed_amd import parallel
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    m = _toy_module([("a.weight", (2, 2)), ("b.weight", (3,))])
+    m.flat_grad.copy_(torch.arange(7.0))
+    plain = parallel.GradArena([m], tail_floats=4)
+    plain.begin_early(); plain.finish()
+    forced = parallel.GradArena([m], tail_floats=4, exchange_single_rank=True)
+    forced.begin_early(); forced.finish()
+    q.put((plain.exchanges, forced.exchanges, bool(torch.equal(forced.flat, torch.arange(7.0)))))
+    dist.destroy_process_group()
+
+
+def test_single_rank_group_can_be_made_to_exchange():
+    """exchange_single_rank: the early + tail all-reduces run (identity) in a group of one rank -- what the GPU test uses
+    to put begin_early / finish through RCCL on a one-GPU box"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_rank_worker, args=(31500 + (os.getpid() % 2000), q))
+    p.start()
+    plain, forced, same = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0 and plain == 0 and forced == 2 and same

@@ -1,3 +1,6 @@
+# the profiler's preloaded tool initialises HIP before python starts: set the hardware-queue count the step's streams
+# expect here, not at import (bsed_amd/_lib.py only warns when it is too late)
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 python3 $R/tools/block0_bench.py 5 > $R/gpurun_out/b0_time.log 2>&1

@@ -1,4 +1,7 @@
 # PMC passes over the stft->mel kernel at the bench shape (256 clips x 10 s at 22.05 kHz): tools/pmc_mel.sh <tag>
+# the profiler's preloaded tool initialises HIP before python starts: set the hardware-queue count the step's streams
+# expect here, not at import (bsed_amd/_lib.py only warns when it is too late)
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 tag=${1:-mel}

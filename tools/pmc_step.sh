@@ -1,6 +1,9 @@
 #!/bin/bash
 # one PMC pass of the headline bench: per-kernel VALU / MFMA / LDS activity and wave residency
 #   bash tools/pmc_step.sh <tag>     (through gpurun, from the repo root; results under gpurun_out/<tag>_pmc_sq)
+# the profiler's preloaded tool initialises HIP before python starts: set the hardware-queue count the step's streams
+# expect here, not at import (bsed_amd/_lib.py only warns when it is too late)
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 set -u
 TAG=${1:-sq}
 R=${GRAFT_REPO_ROOT:-$(pwd)}

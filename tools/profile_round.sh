@@ -1,6 +1,9 @@
 #!/bin/bash
 # Round profile on the GPU box: rocprofv3 kernel stats + PMC passes of the headline bench, bench lines of every mode.
 #   bash tools/profile_round.sh r02        (run from the repo root through gpurun; results under gpurun_out/<tag>_*)
+# the profiler's preloaded tool initialises HIP before python starts: set the hardware-queue count the step's streams
+# expect here, not at import (bsed_amd/_lib.py only warns when it is too late)
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 set -u
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
