@@ -602,8 +602,8 @@ extern "C" int bsed_igemm3(const BsedIgemmDesc* desc, void* stream) {
 // stats (STATS epilogue) has G rows (one per workgroup), not one per tile
 extern "C" int bsed_pack_weight3s(const float* src, void* dst, int ntaps, int K, int N, int NP, long s_tap, long s_k,
                                   long s_n, void* stream) {
-  BSED_CHECK_ARG(src && dst && ntaps > 0 && (K == 16 || K == 32) && N > 0 && NP >= N && NP % 32 == 0,
-                 "bsed_pack_weight3s: K must be 16 or 32, NP a multiple of 32 >= N");
+  BSED_CHECK_ARG(src && dst && ntaps > 0 && K > 0 && K % 16 == 0 && N > 0 && NP >= N && NP % 32 == 0,
+                 "bsed_pack_weight3s: K must be a multiple of 16, NP a multiple of 32 >= N");
   const long total = (long)(NP / 32) * ntaps * (K / 16) * 64;
   hipLaunchKernelGGL(pack_weight3s_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
                      (unsigned short*)dst, ntaps, K / 16, N, NP, s_tap, s_k, s_n);

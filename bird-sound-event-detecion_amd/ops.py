@@ -328,8 +328,19 @@ def _pack_store(key, dst, src, kind, ntaps, K, N, s_tap, s_k, s_n):
             _pack_plan.used.add(key)
 
 
+def igemm3_nsplit():
+    """True: ops.igemm3 runs the round-3 kernel (csrc/igemm3n.hip: a wave owns 32 output channels, weight fragments
+    straight from global memory, one barrier per 32-channel chunk) and pack_weight3 emits its fragment-order table;
+    BSED_IGEMM3N=0 (or 256-position tiles, IGEMM3_RB) = the slab kernel of rounds 1-2 (csrc/igemm3.hip)."""
+    import os
+    return os.environ.get("BSED_IGEMM3N", "1") != "0" and IGEMM3_RB["rb"] != 2
+
+
 def pack_weight3(src, ntaps, K, N, s_tap, s_k, s_n):
-    """bf16 hi/lo split weights for igemm3: uint16 (ntaps, K/32, NP, 64)"""
+    """bf16 hi/lo split weights for igemm3: uint16 (ntaps, K/32, NP, 64), or -- for the N-split kernel -- the
+    fragment-order table of pack_weight3s, int16 (NP/32, ntaps, K/16, 2, 64, 8)"""
+    if igemm3_nsplit():
+        return pack_weight3s(src, ntaps, N, s_tap, s_k, s_n, K=K)
     key = ("w3", src.data_ptr(), L.stream().value, ntaps, K, N, s_tap, s_k, s_n)
     hit = _pack_lookup(key)
     if hit is not None:
@@ -395,6 +406,8 @@ def igemm3s(inp, wtab, N, NB, H, W, taps, bias=None, epilogue=EPI_PLAIN):
 def igemm3(inp, w3, N, NB, H, W, CIN, taps, bias=None, epilogue=EPI_PLAIN, valid=None):
     """3x3 conv forward / dgrad on the bf16 matrix cores with split-fp32 operands.  Returns (out, stats or None).
     valid: see igemm."""
+    if w3.dim() == 6:
+        return _igemm3n(inp, w3, N, NB, H, W, CIN, taps, bias, epilogue, valid)
     d = IgemmDesc()
     TH, TW = tile_for(W)
     NP = w3.shape[2]
@@ -427,6 +440,50 @@ def igemm3(inp, w3, N, NB, H, W, CIN, taps, bias=None, epilogue=EPI_PLAIN, valid
     pv = 12 if rb == 2 or need > 9 else (9 if need > 6 else 6)
     _launch((f"igemm3_kernel<{bn}, {1 if epilogue == EPI_STATS else 0}, {rb}, {pv}>", len(taps), CIN, N, H, W),
             2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call("bsed_igemm3", ctypes.byref(d), L.stream()))
+    return out, stats
+
+
+IGEMM3N_WPE = {"wpe": None}   # A/B knob (set_igemm3n_wpe)
+
+
+def set_igemm3n_wpe(wpe):
+    """A/B knob of the BN = 128 build: 2 / 3 = built for that many waves per SIMD whatever the shape; + 8 = no raised
+    wave priority outside the MFMA loop; 0 / None = default"""
+    IGEMM3N_WPE["wpe"] = wpe
+    L.lib().bsed_igemm3n_set_wpe(_i(wpe or 0))
+
+
+def _igemm3n(inp, wtab, N, NB, H, W, CIN, taps, bias, epilogue, valid):
+    """bsed_igemm3n: wtab = pack_weight3s table of the layer (K = CIN).  Returns (out, stats (rows,2,N) or None)."""
+    d = IgemmDesc()
+    TH, TW = tile_for(W)
+    NP = wtab.shape[0] * 32
+    if wtab.shape[2] * 16 != CIN or wtab.shape[1] != len(taps):
+        raise L.BsedError(f"igemm3: weight table packed for K={wtab.shape[2] * 16}, {wtab.shape[1]} taps; "
+                          f"called with CIN={CIN}, {len(taps)} taps")
+    dev = inp.device
+    out = (torch.zeros if valid else torch.empty)((NB, H, W, N), device=dev, dtype=torch.float32)
+    if valid:
+        d.valid_h, d.valid_w = valid
+    d.in_pitch, d.out_pitch, d.e_pitch = CIN, N, N
+    d.NB, d.H, d.W, d.CIN, d.N, d.NP = NB, H, W, CIN, N, NP
+    d.TH, d.TW = TH, TW
+    d.hh = max(abs(t[0]) for t in taps); d.hw = max(abs(t[1]) for t in taps)
+    d.ntaps = len(taps)
+    for i, (a, b) in enumerate(taps):
+        d.dh[i], d.dw[i] = a, b
+    d.ph = d.pw = 1; d.Hp, d.Wp = H, W
+    d.epilogue = epilogue
+    if IGEMM3N_WPE.get("stamp") is not None:   # diagnostic builds only (tools/conv_stamp.py, -DI3N_STAMP)
+        d.e_src = IGEMM3N_WPE["stamp"].data_ptr()
+    d.in_ = _dp(inp); d.w = wtab.data_ptr(); d.bias = _p(bias); d.out = _p(out)
+    rows = L.lib().bsed_igemm3n_stats_rows(ctypes.byref(d))
+    var = L.lib().bsed_igemm3n_variant(ctypes.byref(d))
+    stats = torch.empty((rows, 2, N), device=dev, dtype=torch.float32) if epilogue == EPI_STATS else None
+    d.stats = _p(stats)
+    _launch((f"igemm3n_kernel<{var & 15}, {(var >> 4) & 15}, {1 if epilogue == EPI_STATS else 0}, {(var >> 8) & 15}, "
+             f"{1 if len(taps) == 9 else 0}, {(var >> 12) & 15}>", len(taps), CIN, N, H, W),
+            2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call("bsed_igemm3n", ctypes.byref(d), L.stream()))
     return out, stats
 
 

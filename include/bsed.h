@@ -140,6 +140,16 @@ typedef struct BsedPackJob {
 } BsedPackJob;
 int bsed_pack_weights_batch(const BsedPackJob* jobs /*host*/, int njobs, void* stream);
 int bsed_igemm3s(const BsedIgemmDesc* desc, int G, void* stream);
+/* The same contraction as bsed_igemm3 (same reference layers: src/models/CNN.py:46-47, the seven nn.Conv2d; GRU input
+ * projections src/models/RNN.py:7-16) in the round-3 structure (csrc/igemm3n.hip): a wave owns 32 output channels and
+ * fetches their weight fragments straight from global memory (w = bsed_pack_weight3s table, K any multiple of 32), the
+ * activation patch is double-buffered in LDS, one barrier per 32-channel chunk.  `out` is bit-identical to
+ * bsed_igemm3's; STATS writes bsed_igemm3n_stats_rows(desc) partial rows of (2, N). */
+int bsed_igemm3n(const BsedIgemmDesc* desc /*host*/, void* stream);
+int bsed_igemm3n_stats_rows(const BsedIgemmDesc* desc /*host: NB, H, W, TH, TW, NP*/);
+int bsed_igemm3n_variant(const BsedIgemmDesc* desc);   /* NWN | MW << 4 | PV << 8 | WPE << 12 of the build */
+void bsed_igemm3n_set_wpe(int knob);  /* A/B knob: 2 / 3 = the BN = 128 build for that many waves per SIMD whatever the
+                                       * shape, + 8 = no raised wave priority outside the MFMA loop, 0 = default */
 int bsed_igemm3s_auto_g(void);
 int bsed_igemm3s_auto_g2(int CIN, int N);   /* per shape (resident workgroups differ with the LDS footprint) */
 
