@@ -411,10 +411,21 @@ __global__ void glu3_pack_frags_kernel(const float* __restrict__ w, bf16x8* __re
 __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params P, const bf16x8* __restrict__ table,
                                                                 float* __restrict__ dlin) {
   constexpr int C = 128, NT = 4, KS = 8;
-  // (runtime tile geometry, read from the parameter block exactly as in round 1, on purpose: builds of this kernel
-  // whose geometry was a compile-time constant or was derived from P.lgTW by shifts were NOT bitwise repeatable on
-  // MI355X -- whole elements of g / d_lin changed between two runs, with every tolerance-based test green -- while
-  // this source is; tests/test_glu_repeat_gpu.py guards every instance that is built)
+#ifdef G3N_LGTW   // diagnostic builds (tools/build_variant.sh): tile geometry as a compile-time constant
+  constexpr int g3n_lgTW = G3N_LGTW, g3n_TW = 1 << G3N_LGTW;
+#else
+  const int g3n_lgTW = P.lgTW, g3n_TW = P.TW;
+#endif
+  // Tile geometry is read from the parameter block (-DG3N_LGTW=<n>: compile-time, diagnostic).  Round 2 found builds
+  // with compile-time geometry NOT bitwise repeatable (whole elements of g / d_lin changed between launches with every
+  // tolerance test green).  Round 3 reproduced it (G3N_LGTW=4, 216 x 16 map: EVERY launch differs -- the pool / dropout
+  // mask of the first row group flips for lanes 48..63 of channel tiles 1..3) and ruled out, by assembling patched
+  // listings (tools/asm_variant.sh), every wait-state explanation: an s_nop after each vector instruction of the
+  // epilogue, after each v_cmp, before each s_and_b64, after each load, s_waitcnt 0 everywhere -- none changes it.  It
+  // is a code-generation problem of hipcc 7.2 tied to the SLP vectorizer's packed (v_pk_* with op_sel swizzles) form
+  // of this epilogue: with -fno-slp-vectorize (csrc/build.sh, this file) BOTH geometries are bit-repeatable at all
+  // four tile widths over 100 launches each (tools/glu3n_repeat.py), and the kernel is 5-12 % faster.  Compile-time
+  // geometry is slower here (hoisted index arithmetic spills: 533 vs 423 us at 216 x 16), so it stays a runtime value.
   constexpr int DQ = 2 * 16 + 8;  // ushorts per row of the 16-channel chunk tile: 16 hi | 16 lo | 8 pad (80 B = 5 x 16 B)
   extern __shared__ __align__(16) unsigned char smem_raw[];
   bf16x8* WF = reinterpret_cast<bf16x8*>(smem_raw);
@@ -456,7 +467,7 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
     f32x16 acc[NT];
     {
       bf16x8 a_hi[KS], a_lo[KS];
-      load_a_frags<C>(P, P.lgTW, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
+      load_a_frags<C>(P, g3n_lgTW, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -484,7 +495,7 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int mm = wave * 32 + 8 * rg + lhv + rr;
-        const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (P.TW - 1));
+        const int gh = th0 + (mm >> g3n_lgTW), gw = tw0 + (mm & (g3n_TW - 1));
         const int gph = gh >> sph, gpw = gw >> spw;
         mk[rr] = (gh < P.H && gph < P.Hp && gpw < P.Wp) ? inv_pool : 0.f;
         posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
@@ -557,7 +568,7 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int mm = wave * 32 + 8 * rg + lhv + rr;
-        const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (P.TW - 1));
+        const int gh = th0 + (mm >> g3n_lgTW), gw = tw0 + (mm & (g3n_TW - 1));
         okf[rr] = gh < P.H ? 1.0f : 0.0f;
         posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
         gdst[rr] = gh < P.H ? P.g + posv[rr] : g3_sink + li;
