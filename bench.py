@@ -139,6 +139,8 @@ def cpu_baseline(sr, seconds, threads):
 SPLIT_KERNEL = re.compile(r"3[a-z]?_kernel")      # *3_kernel / *3n / *3p / *3s: split-fp32 operands on the bf16 cores
 MFMA_KERNEL = re.compile(r"^(igemm|wgrad|glu_fwd3|glu_bwd3|glu_bwd_fused|gru_fwd_mfma|gru_bwd_mfma|glu16|b0_fwd|b0_bwd)")
 ALGORITHMIC_MB_PER_CLIP = {22050: 128.9, 32000: 186.9}     # SURVEY.md 8(d), fp32 activations, mel stage included
+ALGORITHMIC_MB_PER_CLIP_BF16 = {22050: 65.1, 32000: 94.4}  # SURVEY.md 8(d), bf16 activations (--dtype bf16)
+SINGLE_BF16 = re.compile(r"[<,] ?1>$")   # template instances of the split kernels whose last argument (ABF) is 1: ONE bf16 MFMA per product
 STEP_GFLOP_PER_CLIP = {22050: 7.63, 32000: 11.05}           # SURVEY.md 8(d), train step = fwd + 2 x bwd
 
 
@@ -147,14 +149,16 @@ def kernel_roofline(name, launches, total_ms, flops_total, bytes_total):
     ceiling of a split-fp32 kernel is the dense bf16 peak / 3 (three bf16 MFMAs per fp32 product); fp32-core MFMA kernels
     and plain VALU kernels share the 157.3 TFLOP/s fp32 ceiling."""
     split = SPLIT_KERNEL.search(name) is not None
-    peak_tf = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS
+    single = split and SINGLE_BF16.search(name.strip()) is not None    # the bf16 throughput mode's instances
+    peak_tf = PEAK_BF16_MFMA_TFLOPS if single else (PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS)
     avg_ms = total_ms / launches
     tflops = flops_total / (total_ms * 1e-3) / 1e12
     gbs = bytes_total / (total_ms * 1e-3) / 1e9
     intensity = flops_total / max(bytes_total, 1.0)
     ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
     on_matrix = MFMA_KERNEL.search(name) is not None
-    basis = ("dense bf16 MFMA 2500 / 3 (bf16x3 split-fp32 operands)" if split else
+    basis = ("dense bf16 MFMA 2500 (bf16 activations, one MFMA per product)" if single else
+             "dense bf16 MFMA 2500 / 3 (bf16x3 split-fp32 operands)" if split else
              "fp32 MFMA 157.3 (v_mfma_f32_32x32x2_f32 / 16x16x4_f32, exact fp32)" if on_matrix else "fp32 vector 157.3 (no matrix-core work in this kernel)")
     r = {"traffic": None, "kernel": name, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
          "algorithmic_gflop_per_launch": round(flops_total / launches / 1e9, 3),
@@ -185,6 +189,10 @@ def main():
                     help="crnn = BASELINE configs[2] (the headline metric); mt = configs[3] (student + EMA teacher + "
                          "consistency, half the batch synthetic, half real); ada = configs[4] (domain-adversarial head); "
                          "cnn = configs[1] (CNN-only tagging forward, CRNN_pred, batch 64)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 (default, the parity headline): fp32 tensors, split-fp32 contractions; bf16: the throughput mode "
+                         "BASELINE configs[1-2] name -- bf16 CNN activations in HBM, one bf16 MFMA per product, fp32 accumulation "
+                         "/ statistics / master weights / optimizer (tolerances: tests/test_bf16_mode_gpu.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="mel transform inside the step instead of one step ahead on the feature stream")
@@ -202,6 +210,10 @@ def main():
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 64 if args.mode == "cnn" else 256
+    if args.dtype == "bf16":
+        if args.mode in ("ada",):
+            raise SystemExit("--dtype bf16 covers --mode crnn / mt / cnn (the discriminator has no bf16-activation path)")
+        os.environ["BSED_CONV_MODE"] = "bf16"      # read by CRNN.__init__
 
     t_start = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
@@ -488,12 +500,14 @@ def main():
         per_gpu = value / world
         scale = {"crnn": 1.0, "mt": None, "ada": None}[args.mode]
         if scale is not None:
-            mb, gf = ALGORITHMIC_MB_PER_CLIP[args.sr] * args.seconds / 10.0, STEP_GFLOP_PER_CLIP[args.sr] * args.seconds / 10.0
+            mbt = ALGORITHMIC_MB_PER_CLIP_BF16 if args.dtype == "bf16" else ALGORITHMIC_MB_PER_CLIP
+            mb, gf = mbt[args.sr] * args.seconds / 10.0, STEP_GFLOP_PER_CLIP[args.sr] * args.seconds / 10.0
             extra_fields["roofline_step"] = {
                 "bound": "hbm", "algorithmic_mb_per_clip": round(mb, 1), "achieved": round(per_gpu * mb / 1e3, 1),
                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(per_gpu * mb * 1e6 / (PEAK_HBM_GBS * 1e9), 4),
                 "step_gflop_per_clip": gf, "tflops": round(per_gpu * gf / 1e3, 1),
-                "mfma_frac_bf16x3": round(per_gpu * gf * 1e9 / (PEAK_BF16_MFMA_TFLOPS / 3 * 1e12), 4)}
+                ("mfma_frac_bf16" if args.dtype == "bf16" else "mfma_frac_bf16x3"):
+                    round(per_gpu * gf * 1e9 / (PEAK_BF16_MFMA_TFLOPS / (1 if args.dtype == "bf16" else 3) * 1e12), 4)}
     workload = {
         "crnn": "waveform->STFT/mel/dB->CRNN(7 conv/BN/GLU/pool + 2xBiGRU128)->Predictor->BCE strong+weak"
                 "->backward->Adam; BASELINE configs[2] (main_baseline.py train step on SYN)",
@@ -511,7 +525,7 @@ def main():
         "value": round(value, 2), "unit": "clips/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "contraction_mode": os.environ.get("BSED_CONV_MODE", "bf16x3"),
         "config": {"workload": workload, "mode": args.mode,
                    "clip_seconds": args.seconds, "sr": args.sr, "frames": T, "out_frames": Tp,

@@ -282,7 +282,7 @@ struct B0Conv {
 // forward: x -> conv -> BN-apply -> Linear -> gate -> dropout -> PH x pw average pool -> pooled
 // ---------------------------------------------------------------------------------------------
 #define B0F_THREADS 512
-template <int PH, bool SMALL>
+template <int PH, bool SMALL, int ABF>   // ABF: the pooled output is a bf16 tensor (bf16 mode)
 __global__ __launch_bounds__(B0F_THREADS) void b0_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ cw, const float* __restrict__ cb,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ wg,
@@ -350,7 +350,9 @@ __global__ __launch_bounds__(B0F_THREADS) void b0_fwd_kernel(
     }
     if (ok && (w & (pw - 1)) == 0 && (w >> (pw >> 1)) < Wp) {   // pw is 1 or 2
       const float4 o = make_float4(pooled[0] * inv, pooled[1] * inv, pooled[2] * inv, pooled[3] * inv);
-      if (SMALL) {
+      if (ABF) {
+        act_st4<ABF>(out, (((size_t)b * Hp + hp) * Wp + (w >> (pw >> 1))) * C + 4 * q, f32x4{o.x, o.y, o.z, o.w});
+      } else if (SMALL) {
         const uint32_t ob = (uint32_t)((((b * Hp + hp) * Wp + (w >> (pw >> 1))) * C + 4 * q) << 2);
         *reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + ob) = o;
       } else {
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(B0F_THREADS) void b0_fwd_kernel(
 #endif
 #define B0_TP 20   // pitch of the transpose tiles (floats)
 
-template <int PH, bool SMALL>
+template <int PH, bool SMALL, int ABF>   // ABF: d_pooled is a bf16 tensor (bf16 mode)
 __global__ __launch_bounds__(B0B_THREADS, B0B_WPE) void b0_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ cw, const float* __restrict__ cb,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ wg,
@@ -427,7 +429,10 @@ __global__ __launch_bounds__(B0B_THREADS, B0B_WPE) void b0_bwd_kernel(
     X.template fetch<SMALL>(x, I.b, I.hp * PH, I.ch * (B0B_THREADS / 4) + wave * 16, H, W);
     const int w = min(I.ch * (B0B_THREADS / 4) + col, W - 1);
     const int wpi = min(w >> spw, Wp - 1);
-    if (SMALL) {
+    if (ABF) {
+      const f32x4 t = act_ld4<ABF>(dpool, (((size_t)I.b * Hp + I.hp) * Wp + wpi) * C + 4 * q);
+      nd = make_float4(t[0], t[1], t[2], t[3]);
+    } else if (SMALL) {
       const uint32_t ob = (uint32_t)((((I.b * Hp + I.hp) * Wp + wpi) * C + 4 * q) << 2);
       nd = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dpool) + ob);
     } else {
@@ -603,7 +608,7 @@ extern "C" int bsed_block0_stats(const float* x, const float* cw_t, const float*
 
 extern "C" int bsed_block0_fwd(const float* x, const float* cw, const float* cb, const float* scale, const float* shift,
                                const float* wg, const float* bg, float* out, int B, int H, int W, int CO, int ph, int pw,
-                               float drop_p, uint32_t rng_stream, uint64_t seed, void* stream) {
+                               float drop_p, uint32_t rng_stream, uint64_t seed, int act_bf16, void* stream) {
   BSED_CHECK_ARG(x && cw && cb && scale && shift && wg && bg && out, "bsed_block0_fwd: null tensor");
   BSED_CHECK_ARG(CO == B0_C, "bsed_block0_fwd: built for 16 first-layer channels (got %d)", CO);
   BSED_CHECK_ARG(B > 0 && H > 0 && W > 0 && (ph == 1 || ph == 2) && (pw == 1 || pw == 2) && W % pw == 0 && H >= ph &&
@@ -614,11 +619,12 @@ extern "C" int bsed_block0_fwd(const float* x, const float* cw, const float* cb,
   hipStream_t s = (hipStream_t)stream;
   // SMALL: fewer than 2^28 positions (every tensor below 4 GB, element counters below 2^32): 32-bit offsets
   const bool small = (long)B * H * W < (1L << 28);
-#define B0_LAUNCH_FWD(PH_, SM_)                                                                                      \
-  hipLaunchKernelGGL((b0_fwd_kernel<PH_, SM_>), grid, dim3(B0F_THREADS), 0, s, x, cw, cb, scale, shift, wg, bg, out, B, \
+#define B0_LAUNCH_FWD(PH_, SM_, AB_)                                                                                 \
+  hipLaunchKernelGGL((b0_fwd_kernel<PH_, SM_, AB_>), grid, dim3(B0F_THREADS), 0, s, x, cw, cb, scale, shift, wg, bg, out, B, \
                      H, W, pw, drop_p, rng_stream, seed)
-  if (ph == 2) { if (small) B0_LAUNCH_FWD(2, true); else B0_LAUNCH_FWD(2, false); }
-  else { if (small) B0_LAUNCH_FWD(1, true); else B0_LAUNCH_FWD(1, false); }
+  if (act_bf16) { if (ph == 2) B0_LAUNCH_FWD(2, false, 1); else B0_LAUNCH_FWD(1, false, 1); }
+  else if (ph == 2) { if (small) B0_LAUNCH_FWD(2, true, 0); else B0_LAUNCH_FWD(2, false, 0); }
+  else { if (small) B0_LAUNCH_FWD(1, true, 0); else B0_LAUNCH_FWD(1, false, 0); }
 #undef B0_LAUNCH_FWD
   BSED_LAUNCH_CHECK();
   return BSED_OK;
@@ -627,7 +633,7 @@ extern "C" int bsed_block0_fwd(const float* x, const float* cw, const float* cb,
 extern "C" int bsed_block0_bwd(const float* x, const float* cw, const float* cb, const float* scale, const float* shift,
                                const float* wg, const float* bg, const float* dpool, float* part_dw, float* part_db,
                                float* part_st, float* part_gx, int G, int B, int H, int W, int CO, int ph, int pw,
-                               float drop_p, uint32_t rng_stream, uint64_t seed, void* stream) {
+                               float drop_p, uint32_t rng_stream, uint64_t seed, int act_bf16, void* stream) {
   BSED_CHECK_ARG(x && cw && cb && scale && shift && wg && bg && dpool && part_dw && part_db && part_st && part_gx,
                  "bsed_block0_bwd: null tensor");
   BSED_CHECK_ARG(CO == B0_C, "bsed_block0_bwd: built for 16 first-layer channels (got %d)", CO);
@@ -636,11 +642,13 @@ extern "C" int bsed_block0_bwd(const float* x, const float* cw, const float* cb,
   BSED_CHECK_ARG((long)B * H * W < (1L << 31), "bsed_block0_bwd: too many positions");
   hipStream_t s = (hipStream_t)stream;
   const bool small = (long)B * H * W < (1L << 28);
-#define B0_LAUNCH_BWD(PH_, SM_)                                                                                       \
-  hipLaunchKernelGGL((b0_bwd_kernel<PH_, SM_>), dim3(G), dim3(B0B_THREADS), 0, s, x, cw, cb, scale, shift, wg, bg, dpool, \
+#define B0_LAUNCH_BWD(PH_, SM_, AB_)                                                                                  \
+  hipLaunchKernelGGL((b0_bwd_kernel<PH_, SM_, AB_>), dim3(G), dim3(B0B_THREADS), 0, s, x, cw, cb, scale, shift, wg, bg, dpool, \
                      part_dw, part_db, part_st, part_gx, B, H, W, pw, drop_p, rng_stream, seed)
-  if (ph == 2) { if (small) B0_LAUNCH_BWD(2, true); else B0_LAUNCH_BWD(2, false); }
-  else { if (small) B0_LAUNCH_BWD(1, true); else B0_LAUNCH_BWD(1, false); }
+  if (act_bf16) { if (ph == 2) { if (small) B0_LAUNCH_BWD(2, true, 1); else B0_LAUNCH_BWD(2, false, 1); }
+                  else { if (small) B0_LAUNCH_BWD(1, true, 1); else B0_LAUNCH_BWD(1, false, 1); } }
+  else if (ph == 2) { if (small) B0_LAUNCH_BWD(2, true, 0); else B0_LAUNCH_BWD(2, false, 0); }
+  else { if (small) B0_LAUNCH_BWD(1, true, 0); else B0_LAUNCH_BWD(1, false, 0); }
 #undef B0_LAUNCH_BWD
   BSED_LAUNCH_CHECK();
   return BSED_OK;

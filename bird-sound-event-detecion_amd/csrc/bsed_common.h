@@ -72,6 +72,56 @@ __device__ __forceinline__ void bsed_split2(float a, float b, uint32_t& hi, uint
 }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#if defined(__HIPCC__)
+// ----------------------------------------------------------------------------------------------
+// Activation storage of a kernel instance: ABF = 0 fp32, ABF = 1 bf16 (the "bf16" throughput mode of BASELINE
+// configs[1-2]: conv outputs, pooled outputs and their gradients are bf16 in HBM; accumulation, BatchNorm statistics,
+// master weights and the optimizer stay fp32).  The C ABI keeps `float*` parameter types; with act_bf16 set they
+// point to bf16 tensors.
+// ----------------------------------------------------------------------------------------------
+typedef uint32_t bsed_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float bsed_bf2f(uint32_t h16) { return __uint_as_float(h16 << 16); }
+template <int ABF> __device__ __forceinline__ float act_ld(const float* base, size_t i) {
+  if (ABF) return bsed_bf2f(reinterpret_cast<const unsigned short*>(base)[i]);
+  return base[i];
+}
+template <int ABF> __device__ __forceinline__ void act_st(float* base, size_t i, float v) {
+  if (ABF) reinterpret_cast<__bf16*>(base)[i] = (__bf16)v;   // round to nearest even
+  else base[i] = v;
+}
+// 8 consecutive elements starting at element i (i a multiple of 8): one 16-byte load (bf16) or two (fp32)
+template <int ABF> __device__ __forceinline__ void act_ld8(const float* base, size_t i, float* v) {
+  if (ABF) {
+    const bsed_u32x4 r = *reinterpret_cast<const bsed_u32x4*>(reinterpret_cast<const unsigned short*>(base) + i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(r[q] << 16); v[2 * q + 1] = __uint_as_float(r[q] & 0xFFFF0000u); }
+  } else {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(base + i), b = *reinterpret_cast<const f32x4*>(base + i + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  }
+}
+// 4 consecutive elements starting at element i (i a multiple of 4)
+template <int ABF> __device__ __forceinline__ f32x4 act_ld4(const float* base, size_t i) {
+  if (ABF) {
+    const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + i);
+    return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xFFFF0000u), __uint_as_float(r.y << 16),
+                 __uint_as_float(r.y & 0xFFFF0000u)};
+  }
+  return *reinterpret_cast<const f32x4*>(base + i);
+}
+template <int ABF> __device__ __forceinline__ void act_st4(float* base, size_t i, f32x4 v) {
+  if (ABF) {
+    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    uint2 r;
+    r.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bsed_bf16x2));
+    r.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bsed_bf16x2));
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + i) = r;
+  } else {
+    *reinterpret_cast<f32x4*>(base + i) = v;
+  }
+}
+#endif
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 #if defined(__HIPCC__)

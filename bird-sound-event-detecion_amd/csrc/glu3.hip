@@ -66,6 +66,16 @@ __device__ __forceinline__ void acc_handoff_fence(f32x16 (&acc)[NT]) {
   else if constexpr (NT == 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]) :: "memory");
   else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) :: "memory");
 }
+// one product of split operands: three MFMAs (lo*hi, hi*lo, hi*hi), or -- bf16 mode -- the hi*hi one alone
+template <int ABF>
+__device__ __forceinline__ f32x16 mfma_sp(const bf16x8& a_hi, const bf16x8& a_lo, const bf16x8& b_hi, const bf16x8& b_lo,
+                                          f32x16 acc) {
+  if (!ABF) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc, 0, 0, 0);
+}
 __device__ __forceinline__ int crow3g(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 __device__ __forceinline__ uint32_t rne_bits(float x) {  // bf16 round-to-nearest-even, result in the UPPER 16 bits
   const uint32_t u = __float_as_uint(x);
@@ -112,20 +122,17 @@ __device__ __forceinline__ void build_weight_frags(const float* __restrict__ w, 
 }
 
 // GEMM1 A fragments of this wave's 32 positions: BatchNorm-applied, split
-template <int C>
+template <int C, int ABF>
 __device__ __forceinline__ void load_a_frags(const Glu3Params& P, int lgTW, const float* s_sc, const float* s_sh, int nb,
                                              int th0, int tw0, int wave, int li, int lh, bf16x8* a_hi, bf16x8* a_lo) {
   constexpr int KS = C / 16;
   const int mA = wave * 32 + li;
   const int gh = th0 + (mA >> lgTW), gw = tw0 + (mA & ((1 << lgTW) - 1));
   const bool ok = gh < P.H;
-  const float* rp = P.y + (((size_t)nb * P.H + (ok ? gh : 0)) * P.W + gw) * C + 8 * lh;
-  float4 raw[KS][2];
+  const size_t rp = (((size_t)nb * P.H + (ok ? gh : 0)) * P.W + gw) * C + 8 * lh;
+  float raw[KS][8];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    raw[ks][0] = *reinterpret_cast<const float4*>(rp + 16 * ks);
-    raw[ks][1] = *reinterpret_cast<const float4*>(rp + 16 * ks + 4);
-  }
+  for (int ks = 0; ks < KS; ++ks) act_ld8<ABF>(P.y, rp + 16 * ks, raw[ks]);
   const float okf = ok ? 1.0f : 0.0f;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
@@ -134,10 +141,10 @@ __device__ __forceinline__ void load_a_frags(const Glu3Params& P, int lgTW, cons
     const float4 h0 = *reinterpret_cast<const float4*>(s_sh + 16 * ks + 8 * lh);
     const float4 h1 = *reinterpret_cast<const float4*>(s_sh + 16 * ks + 8 * lh + 4);
     float v[8];
-    v[0] = fmaf(raw[ks][0].x, s0.x, h0.x) * okf; v[1] = fmaf(raw[ks][0].y, s0.y, h0.y) * okf;
-    v[2] = fmaf(raw[ks][0].z, s0.z, h0.z) * okf; v[3] = fmaf(raw[ks][0].w, s0.w, h0.w) * okf;
-    v[4] = fmaf(raw[ks][1].x, s1.x, h1.x) * okf; v[5] = fmaf(raw[ks][1].y, s1.y, h1.y) * okf;
-    v[6] = fmaf(raw[ks][1].z, s1.z, h1.z) * okf; v[7] = fmaf(raw[ks][1].w, s1.w, h1.w) * okf;
+    v[0] = fmaf(raw[ks][0], s0.x, h0.x) * okf; v[1] = fmaf(raw[ks][1], s0.y, h0.y) * okf;
+    v[2] = fmaf(raw[ks][2], s0.z, h0.z) * okf; v[3] = fmaf(raw[ks][3], s0.w, h0.w) * okf;
+    v[4] = fmaf(raw[ks][4], s1.x, h1.x) * okf; v[5] = fmaf(raw[ks][5], s1.y, h1.y) * okf;
+    v[6] = fmaf(raw[ks][6], s1.z, h1.z) * okf; v[7] = fmaf(raw[ks][7], s1.w, h1.w) * okf;
     split_pack8(v, a_hi[ks], a_lo[ks]);
   }
 }
@@ -153,7 +160,7 @@ __device__ __forceinline__ float drop_mul32(uint32_t e, uint32_t key, uint32_t t
 #ifndef G3_B32_WPE
 #define G3_B32_WPE 3
 #endif
-template <int C, int LGTW>
+template <int C, int LGTW, int ABF>
 __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3_kernel(const Glu3Params P) {
   constexpr int NT = C / 32, KS = C / 16;
   // LGTW >= 0: the tile width is a compile-time constant (16 for every block of the reference network with more than
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
     f32x16 acc[NT];
     {
       bf16x8 a_hi[KS], a_lo[KS];
-      load_a_frags<C>(P, lgTW, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
+      load_a_frags<C, ABF>(P, lgTW, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -220,9 +227,7 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
         for (int j = 0; j < NT; ++j) {
           const bf16x8 b_hi = WF[((j * KS + ks) * 2 + 0) * 64 + lane];
           const bf16x8 b_lo = WF[((j * KS + ks) * 2 + 1) * 64 + lane];
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[ks], b_hi, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_lo, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_hi, acc[j], 0, 0, 0);
+          acc[j] = mfma_sp<ABF>(a_hi[ks], a_lo[ks], b_hi, b_lo, acc[j]);
         }
     }
 
@@ -248,8 +253,8 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
           const uint32_t dpo = ((uint32_t)(nb * P.Hp + min(gph, P.Hp - 1)) * (uint32_t)P.Wp + min(gpw, P.Wp - 1)) * C + li;
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
-            dv[rr][j] = P.dpool[dpo + 32 * j];
-            yv[rr][j] = P.y[posv[rr] + 32 * j];
+            dv[rr][j] = act_ld<ABF>(P.dpool, dpo + 32 * j);
+            yv[rr][j] = act_ld<ABF>(P.y, posv[rr] + 32 * j);
           }
         }
 #pragma unroll
@@ -292,9 +297,7 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
       for (int j = 0; j < NT; ++j) {
         const bf16x8 b_hi = WB[((j * KS + ks) * 2 + 0) * 64 + lane];
         const bf16x8 b_lo = WB[((j * KS + ks) * 2 + 1) * 64 + lane];
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_lo, b_hi, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_hi, b_lo, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_hi, b_hi, acc[j], 0, 0, 0);
+        acc[j] = mfma_sp<ABF>(d_hi, d_lo, b_hi, b_lo, acc[j]);
       }
     }
     wave_lds_fence();
@@ -306,9 +309,7 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
       for (int jn = 0; jn < NT; ++jn)
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-          acc3[jn][jc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da_lo[jn][f], xb_hi[jc][f], acc3[jn][jc], 0, 0, 0);
-          acc3[jn][jc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da_hi[jn][f], xb_lo[jc][f], acc3[jn][jc], 0, 0, 0);
-          acc3[jn][jc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da_hi[jn][f], xb_hi[jc][f], acc3[jn][jc], 0, 0, 0);
+          acc3[jn][jc] = mfma_sp<ABF>(da_hi[jn][f], da_lo[jn][f], xb_hi[jc][f], xb_lo[jc][f], acc3[jn][jc]);
         }
 
     // ---- epilogue 2: write g, BatchNorm-backward sums (y re-read: cache-hot)
@@ -317,22 +318,24 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
       float yv[4][NT], okf[4];
       uint32_t posv[4];
       float* gdst[4];
+      uint32_t gidx[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int mm = wave * 32 + 8 * rg + lhv + rr;
         const int gh = th0 + (mm >> lgTW), gw = tw0 + (mm & (TWc - 1));
         okf[rr] = gh < P.H ? 1.0f : 0.0f;
         posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
-        gdst[rr] = gh < P.H ? P.g + posv[rr] : g3_sink + li;  // rows below the image store to a sink: no branch
+        gdst[rr] = gh < P.H ? P.g : g3_sink;  // rows below the image store to a sink: no branch
+        gidx[rr] = gh < P.H ? posv[rr] : (uint32_t)li;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) yv[rr][j] = P.y[posv[rr] + 32 * j];
+        for (int j = 0; j < NT; ++j) yv[rr][j] = act_ld<ABF>(P.y, posv[rr] + 32 * j);
       }
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const float gv = acc[j][4 * rg + rr] * okf[rr];  // (rows below the image carry g = 0 anyway: d_lin = gate = 0)
-          gdst[rr][32 * j] = gv;
+          act_st<ABF>(gdst[rr], gidx[rr] + 32 * j, gv);
           sgs[j] += gv;
           sgy[j] = fmaf(gv, yv[rr][j], sgy[j]);
         }
@@ -408,6 +411,7 @@ __global__ void glu3_pack_frags_kernel(const float* __restrict__ w, bf16x8* __re
 // Eight waves share the 128 KB of weights: waves 0-3 and 4-7 work on two different 128-position tiles (no barrier
 // inside the tile loop), which puts two waves on every SIMD instead of one.
 #define G3N_THREADS 512
+template <int ABF>
 __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params P, const bf16x8* __restrict__ table,
                                                                 float* __restrict__ dlin) {
   constexpr int C = 128, NT = 4, KS = 8;
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
     f32x16 acc[NT];
     {
       bf16x8 a_hi[KS], a_lo[KS];
-      load_a_frags<C>(P, g3n_lgTW, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
+      load_a_frags<C, ABF>(P, g3n_lgTW, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -478,9 +482,7 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
         for (int j = 0; j < NT; ++j) {
           const bf16x8 b_hi = WF[((j * KS + ks) * 2 + 0) * 64 + lane];
           const bf16x8 b_lo = WF[((j * KS + ks) * 2 + 1) * 64 + lane];
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[ks], b_hi, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_lo, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_hi, acc[j], 0, 0, 0);
+          acc[j] = mfma_sp<ABF>(a_hi[ks], a_lo[ks], b_hi, b_lo, acc[j]);
         }
     }
 
@@ -492,6 +494,7 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
       float dv[4][NT], yv[4][NT], mk[4];
       uint32_t posv[4];
       float* dlrow[4];
+      uint32_t dlidx[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int mm = wave * 32 + 8 * rg + lhv + rr;
@@ -499,12 +502,13 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
         const int gph = gh >> sph, gpw = gw >> spw;
         mk[rr] = (gh < P.H && gph < P.Hp && gpw < P.Wp) ? inv_pool : 0.f;
         posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
-        dlrow[rr] = gh < P.H ? dlin + posv[rr] : g3_sink + li;
+        dlrow[rr] = gh < P.H ? dlin : g3_sink;
+        dlidx[rr] = gh < P.H ? posv[rr] : (uint32_t)li;
         const uint32_t dpo = ((uint32_t)(nb * P.Hp + min(gph, P.Hp - 1)) * (uint32_t)P.Wp + min(gpw, P.Wp - 1)) * C + li;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          dv[rr][j] = P.dpool[dpo + 32 * j];
-          yv[rr][j] = P.y[posv[rr] + 32 * j];
+          dv[rr][j] = act_ld<ABF>(P.dpool, dpo + 32 * j);
+          yv[rr][j] = act_ld<ABF>(P.y, posv[rr] + 32 * j);
         }
       }
 #pragma unroll
@@ -522,7 +526,7 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
             const float dl = dres * sg;
             acc[j][r] = dres * lin * sg * (1.0f - sg);
             sdb[j] += dl;
-            dlrow[rr][32 * j] = dl;
+            act_st<ABF>(dlrow[rr], dlidx[rr] + 32 * j, dl);
             dl2[e] = dl;
           }
           split_pack2(dl2[0], dl2[1], dph[j][2 * rg + rp], dpl[j][2 * rg + rp]);
@@ -552,9 +556,7 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
       for (int j = 0; j < NT; ++j) {
         const bf16x8 b_hi = WB[((j * KS + q) * 2 + 0) * 64 + lane];
         const bf16x8 b_lo = WB[((j * KS + q) * 2 + 1) * 64 + lane];
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_lo, b_hi, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_hi, b_lo, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d_hi, b_hi, acc[j], 0, 0, 0);
+        acc[j] = mfma_sp<ABF>(d_hi, d_lo, b_hi, b_lo, acc[j]);
       }
       wave_lds_fence();
     }
@@ -565,22 +567,24 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
       float yv[4][NT], okf[4];
       uint32_t posv[4];
       float* gdst[4];
+      uint32_t gidx[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int mm = wave * 32 + 8 * rg + lhv + rr;
         const int gh = th0 + (mm >> g3n_lgTW), gw = tw0 + (mm & (g3n_TW - 1));
         okf[rr] = gh < P.H ? 1.0f : 0.0f;
         posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
-        gdst[rr] = gh < P.H ? P.g + posv[rr] : g3_sink + li;
+        gdst[rr] = gh < P.H ? P.g : g3_sink;
+        gidx[rr] = gh < P.H ? posv[rr] : (uint32_t)li;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) yv[rr][j] = P.y[posv[rr] + 32 * j];
+        for (int j = 0; j < NT; ++j) yv[rr][j] = act_ld<ABF>(P.y, posv[rr] + 32 * j);
       }
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const float gv = acc[j][4 * rg + rr] * okf[rr];
-          gdst[rr][32 * j] = gv;
+          act_st<ABF>(gdst[rr], gidx[rr] + 32 * j, gv);
           sgs[j] += gv;
           sgy[j] = fmaf(gv, yv[rr][j], sgy[j]);
         }
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
 // GEMM1 as above; the epilogue works in the C layout where a lane holds, for its channel, four consecutive positions
 // per register group: the (1,2) and (2,2) pooling windows of a tile row are lane-local (the vertical partner of a
 // position sits 8 registers further at TW = 16, 4 at TW = 8, 2 at TW = 2), so pooling needs neither LDS nor shuffles.
-template <int C, int LGTW>
+template <int C, int LGTW, int ABF>
 __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Params P) {
   constexpr int NT = C / 32, KS = C / 16;
   // LGTW >= 0: the tile width is a compile-time constant (16 for every block of the reference network with more than
@@ -672,21 +676,31 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
     {
       bf16x8 a_hi[KS], a_lo[KS];
       if constexpr (STAGE) {
-        constexpr int Q = C / 4, NL = 32 * Q / 64;  // float4 per row, loads per lane
-        f32x4 raw[NL];
+        // 16-byte pieces per row (4 fp32 / 8 bf16 channels each) and per lane
+        constexpr int EP = ABF ? 8 : 4, Q = C / EP, NL = 32 * Q / 64;
+        f32x4 raw[NL][ABF ? 2 : 1];
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
           const int e = lane + 64 * k, pr = e / Q, q = e % Q;
           const int mm = wave * 32 + pr;
           const int gh = th0 + (mm >> lgTW), gw = tw0 + (mm & (TW - 1));
-          raw[k] = gh < P.H ? *reinterpret_cast<const f32x4*>(P.y + (((size_t)nb * P.H + gh) * P.W + gw) * C + 4 * q)
-                            : f32x4{0.f, 0.f, 0.f, 0.f};
+          const size_t o = (((size_t)nb * P.H + min(gh, P.H - 1)) * P.W + gw) * C + EP * q;
+          const float okr = gh < P.H ? 1.0f : 0.0f;
+          if (ABF) {
+            float v8[8];
+            act_ld8<ABF>(P.y, o, v8);
+            raw[k][0] = f32x4{v8[0], v8[1], v8[2], v8[3]} * okr;
+            raw[k][ABF ? 1 : 0] = f32x4{v8[4], v8[5], v8[6], v8[7]} * okr;
+          } else {
+            raw[k][0] = *reinterpret_cast<const f32x4*>(P.y + o) * okr;
+          }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous tile's reads of the image are done
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
           const int e = lane + 64 * k;
-          *reinterpret_cast<f32x4*>(Ys + (e / Q) * YROW + 4 * (e % Q)) = raw[k];
+          *reinterpret_cast<f32x4*>(Ys + (e / Q) * YROW + EP * (e % Q)) = raw[k][0];
+          if (ABF) *reinterpret_cast<f32x4*>(Ys + (e / Q) * YROW + EP * (e % Q) + 4) = raw[k][ABF ? 1 : 0];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // image complete before other lanes' rows are read
         const int mA = wave * 32 + li;
@@ -707,7 +721,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
           split_pack8(v, a_hi[ks], a_lo[ks]);
         }
       } else {
-        load_a_frags<C>(P, lgTW, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
+        load_a_frags<C, ABF>(P, lgTW, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j)
@@ -719,9 +733,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
         for (int j = 0; j < NT; ++j) {
           const bf16x8 b_hi = WF[((j * KS + ks) * 2 + 0) * 64 + lane];
           const bf16x8 b_lo = WF[((j * KS + ks) * 2 + 1) * 64 + lane];
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[ks], b_hi, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_lo, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ks], b_hi, acc[j], 0, 0, 0);
+          acc[j] = mfma_sp<ABF>(a_hi[ks], a_lo[ks], b_hi, b_lo, acc[j]);
         }
     }
 
@@ -738,7 +750,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
         posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          yv[rr][j] = STAGE ? Ys[(8 * rg + lhv + rr) * YROW + 32 * j + li] : P.y[posv[rr] + 32 * j];
+          yv[rr][j] = STAGE ? Ys[(8 * rg + lhv + rr) * YROW + 32 * j + li] : act_ld<ABF>(P.y, posv[rr] + 32 * j);
       }
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
@@ -760,11 +772,11 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
         const int gh = th0 + (mm >> lgTW), gw = tw0 + (mm & (TW - 1));
         const int gpw = gw >> spw;
         if (gh < P.H && gpw < P.Wp) {
-          float* dst = P.pooled + (((size_t)nb * P.Hp + gh) * P.Wp + gpw) * C + li;
+          const size_t dst = (((size_t)nb * P.Hp + gh) * P.Wp + gpw) * C + li;
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             const float v = P.pw == 2 ? acc[j][r] + acc[j][r | 1] : acc[j][r];
-            dst[32 * j] = v * inv_pool;
+            act_st<ABF>(P.pooled, dst + 32 * j, v * inv_pool);
           }
         }
       }
@@ -779,7 +791,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
         const int gph = gh >> 1, gpw = gw >> spw;
         const bool top = (lr & 1) == 0 && (P.pw == 1 || (gw & 1) == 0);
         if (top && gph < P.Hp && gpw < P.Wp) {
-          float* dst = P.pooled + (((size_t)nb * P.Hp + gph) * P.Wp + gpw) * C + li;
+          const size_t dst = (((size_t)nb * P.Hp + gph) * P.Wp + gpw) * C + li;
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             // (dynamic register offsets are resolved at compile time: r and dr take few values, selected below)
@@ -788,7 +800,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
             else if (dr == 4) v = acc[j][r] + acc[j][(r + 4) & 15] + (P.pw == 2 ? acc[j][r | 1] + acc[j][((r + 4) & 15) | 1] : 0.f);
             else if (dr == 2) v = acc[j][r] + acc[j][(r + 2) & 15] + (P.pw == 2 ? acc[j][r | 1] + acc[j][((r + 2) & 15) | 1] : 0.f);
             else v = acc[j][r] + acc[j][(r + 1) & 15];  // TW = 1 (width-1 maps of the FPN levels): pw = 1
-            dst[32 * j] = v * inv_pool;
+            act_st<ABF>(P.pooled, dst + 32 * j, v * inv_pool);
           }
         }
       }
@@ -796,18 +808,18 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
   }
 }
 
-template <int C>
+template <int C, int ABF>
 static int launch_glu_fwd3(const Glu3Params& P, int G, hipStream_t s) {
   constexpr int NT = C / 32, KS = C / 16;
   const size_t smem = (size_t)NT * KS * 2 * 64 * 16 + 2 * C * sizeof(float) +
                       (C <= 64 ? (size_t)4 * 32 * (C + 4) * sizeof(float) : 0);  // + the waves' staged y rows
   static BsedLdsOnce once, once4;
   if (glu3_const_tw(P)) {
-    BSED_HIP(bsed_max_lds(once4, (const void*)glu_fwd3_kernel<C, 4>));
-    hipLaunchKernelGGL((glu_fwd3_kernel<C, 4>), dim3(G), dim3(G3_THREADS), smem, s, P);
+    BSED_HIP(bsed_max_lds(once4, (const void*)glu_fwd3_kernel<C, 4, ABF>));
+    hipLaunchKernelGGL((glu_fwd3_kernel<C, 4, ABF>), dim3(G), dim3(G3_THREADS), smem, s, P);
   } else {
-    BSED_HIP(bsed_max_lds(once, (const void*)glu_fwd3_kernel<C, -1>));
-    hipLaunchKernelGGL((glu_fwd3_kernel<C, -1>), dim3(G), dim3(G3_THREADS), smem, s, P);
+    BSED_HIP(bsed_max_lds(once, (const void*)glu_fwd3_kernel<C, -1, ABF>));
+    hipLaunchKernelGGL((glu_fwd3_kernel<C, -1, ABF>), dim3(G), dim3(G3_THREADS), smem, s, P);
   }
   BSED_LAUNCH_CHECK();
   return BSED_OK;
@@ -819,16 +831,16 @@ static size_t glu_bwd3_smem() {
   return (size_t)2 * NT * KS * 2 * 64 * 16 + 2 * C * sizeof(float) + (size_t)4 * 32 * (2 * C + 8) * 2;
 }
 
-template <int C>
+template <int C, int ABF>
 static int launch_glu_bwd3(const Glu3Params& P, int G, hipStream_t s) {
   const size_t smem = glu_bwd3_smem<C>();
   static BsedLdsOnce once, once4;
   if (glu3_const_tw(P)) {
-    BSED_HIP(bsed_max_lds(once4, (const void*)glu_bwd3_kernel<C, 4>));
-    hipLaunchKernelGGL((glu_bwd3_kernel<C, 4>), dim3(G), dim3(G3_THREADS), smem, s, P);
+    BSED_HIP(bsed_max_lds(once4, (const void*)glu_bwd3_kernel<C, 4, ABF>));
+    hipLaunchKernelGGL((glu_bwd3_kernel<C, 4, ABF>), dim3(G), dim3(G3_THREADS), smem, s, P);
   } else {
-    BSED_HIP(bsed_max_lds(once, (const void*)glu_bwd3_kernel<C, -1>));
-    hipLaunchKernelGGL((glu_bwd3_kernel<C, -1>), dim3(G), dim3(G3_THREADS), smem, s, P);
+    BSED_HIP(bsed_max_lds(once, (const void*)glu_bwd3_kernel<C, -1, ABF>));
+    hipLaunchKernelGGL((glu_bwd3_kernel<C, -1, ABF>), dim3(G), dim3(G3_THREADS), smem, s, P);
   }
   BSED_LAUNCH_CHECK();
   return BSED_OK;
@@ -862,7 +874,7 @@ extern "C" int bsed_glu_bwd3_auto_g(int C) { return C == 32 ? env_g("BSED_GLU_BW
 extern "C" int bsed_glu_bwd3(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
                              const float* dpool, float* g, float* part_dw, float* part_db, float* part_st, int G,
                              int NB, int H, int W, int C, int TH, int TW, int ph, int pw, float drop_p,
-                             uint32_t rng_stream, uint64_t seed, void* stream) {
+                             uint32_t rng_stream, uint64_t seed, int act_bf16, void* stream) {
   BSED_CHECK_ARG(y && scale && shift && w && bias && dpool && g && part_dw && part_db && part_st,
                  "bsed_glu_bwd3: null tensor");
   BSED_CHECK_ARG(C == 32 || C == 64, "bsed_glu_bwd3: built for C in {32,64} (got %d)", C);
@@ -874,8 +886,9 @@ extern "C" int bsed_glu_bwd3(const float* y, const float* scale, const float* sh
   P.g = g; P.part_dw = part_dw; P.part_db = part_db; P.part_st = part_st; P.pooled = nullptr;
   P.drop_p = drop_p; P.rng_stream = rng_stream; P.seed = seed;
   hipStream_t s = (hipStream_t)stream;
-  if (C == 64) return launch_glu_bwd3<64>(P, G, s);
-  return launch_glu_bwd3<32>(P, G, s);
+  if (act_bf16) return C == 64 ? launch_glu_bwd3<64, 1>(P, G, s) : launch_glu_bwd3<32, 1>(P, G, s);
+  if (C == 64) return launch_glu_bwd3<64, 0>(P, G, s);
+  return launch_glu_bwd3<32, 0>(P, G, s);
 }
 
 extern "C" int bsed_glu_fwd3_auto_g(int C) {
@@ -886,7 +899,7 @@ extern "C" int bsed_glu_fwd3_auto_g(int C) {
 
 extern "C" int bsed_glu_fwd3(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
                              float* pooled, int G, int NB, int H, int W, int C, int TH, int TW, int ph, int pw,
-                             float drop_p, uint32_t rng_stream, uint64_t seed, void* stream) {
+                             float drop_p, uint32_t rng_stream, uint64_t seed, int act_bf16, void* stream) {
   BSED_CHECK_ARG(y && scale && shift && w && bias && pooled, "bsed_glu_fwd3: null tensor");
   BSED_CHECK_ARG(C == 32 || C == 64 || C == 128, "bsed_glu_fwd3: built for C in {32,64,128} (got %d)", C);
   Glu3Params P;
@@ -900,9 +913,10 @@ extern "C" int bsed_glu_fwd3(const float* y, const float* scale, const float* sh
   P.g = nullptr; P.part_dw = nullptr; P.part_db = nullptr; P.part_st = nullptr; P.pooled = pooled;
   P.drop_p = drop_p; P.rng_stream = rng_stream; P.seed = seed;
   hipStream_t s = (hipStream_t)stream;
-  if (C == 128) return launch_glu_fwd3<128>(P, G, s);
-  if (C == 64) return launch_glu_fwd3<64>(P, G, s);
-  return launch_glu_fwd3<32>(P, G, s);
+  if (act_bf16) return C == 128 ? launch_glu_fwd3<128, 1>(P, G, s) : (C == 64 ? launch_glu_fwd3<64, 1>(P, G, s) : launch_glu_fwd3<32, 1>(P, G, s));
+  if (C == 128) return launch_glu_fwd3<128, 0>(P, G, s);
+  if (C == 64) return launch_glu_fwd3<64, 0>(P, G, s);
+  return launch_glu_fwd3<32, 0>(P, G, s);
 }
 
 // C = 128: g, d_lin (for the separate weight-gradient pass), db and BatchNorm-backward partials.  frag_table: 128 KB
@@ -912,7 +926,7 @@ extern "C" size_t bsed_glu_bwd3n_table_bytes(void) { return (size_t)2 * 4 * 8 * 
 extern "C" int bsed_glu_bwd3n(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
                               const float* dpool, float* g, float* dlin, float* part_db, float* part_st,
                               void* frag_table, int G, int NB, int H, int W, int C, int TH, int TW, int ph, int pw,
-                              float drop_p, uint32_t rng_stream, uint64_t seed, void* stream) {
+                              float drop_p, uint32_t rng_stream, uint64_t seed, int act_bf16, void* stream) {
   BSED_CHECK_ARG(y && scale && shift && w && bias && dpool && g && dlin && part_db && part_st && frag_table,
                  "bsed_glu_bwd3n: null tensor");
   BSED_CHECK_ARG(C == 128, "bsed_glu_bwd3n: built for C = 128 (got %d)", C);
@@ -927,9 +941,14 @@ extern "C" int bsed_glu_bwd3n(const float* y, const float* scale, const float* s
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(glu3_pack_frags_kernel, dim3(4 * 8 * 64 / 256), dim3(256), 0, s, w, (bf16x8*)frag_table);
   const size_t smem = bsed_glu_bwd3n_table_bytes() + 2 * 128 * sizeof(float) + (size_t)8 * 32 * (2 * 16 + 8) * 2;
-  static BsedLdsOnce once;
-  BSED_HIP(bsed_max_lds(once, (const void*)glu_bwd3n_kernel));
-  hipLaunchKernelGGL(glu_bwd3n_kernel, dim3(G), dim3(G3N_THREADS), smem, s, P, (const bf16x8*)frag_table, dlin);
+  static BsedLdsOnce once, onceb;
+  if (act_bf16) {
+    BSED_HIP(bsed_max_lds(onceb, (const void*)glu_bwd3n_kernel<1>));
+    hipLaunchKernelGGL(glu_bwd3n_kernel<1>, dim3(G), dim3(G3N_THREADS), smem, s, P, (const bf16x8*)frag_table, dlin);
+  } else {
+    BSED_HIP(bsed_max_lds(once, (const void*)glu_bwd3n_kernel<0>));
+    hipLaunchKernelGGL(glu_bwd3n_kernel<0>, dim3(G), dim3(G3N_THREADS), smem, s, P, (const bf16x8*)frag_table, dlin);
+  }
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }

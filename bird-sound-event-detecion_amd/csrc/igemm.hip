@@ -458,7 +458,8 @@ __device__ __forceinline__ w3_bf16x8 w3_frag(uint32_t a0, uint32_t a1) {
   return __builtin_shufflevector(u, v, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// 4 channels of one position -> the two planes
+// 4 channels of one position -> the two planes (ABF, the bf16 mode: the hi plane alone)
+template <int ABF = 0>
 __device__ __forceinline__ void w3_store4(w3_lds_u16* hi_plane, w3_lds_u16* lo_plane, int o, const float4& v) {
   w3_u32x2 hi, lo;
   uint32_t h0, l0, h1, l1;
@@ -466,7 +467,24 @@ __device__ __forceinline__ void w3_store4(w3_lds_u16* hi_plane, w3_lds_u16* lo_p
   bsed_split2(v.z, v.w, h1, l1);
   hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
   *(w3_lds_u2*)(hi_plane + o) = hi;
-  *(w3_lds_u2*)(lo_plane + o) = lo;
+  if (!ABF) *(w3_lds_u2*)(lo_plane + o) = lo;
+}
+// activation loads / stores through a pointer computed in ELEMENTS from the tensor base (ABF: the tensor is bf16)
+template <int ABF> __device__ __forceinline__ float4 w3_ld4(const float* base, const float* q) {
+  const f32x4 t = act_ld4<ABF>(base, (size_t)(q - base));
+  return make_float4(t[0], t[1], t[2], t[3]);
+}
+template <int ABF> __device__ __forceinline__ void w3_st4(float* base, float* q, const float4& v) {
+  act_st4<ABF>(base, (size_t)(q - base), f32x4{v.x, v.y, v.z, v.w});
+}
+template <int ABF>
+__device__ __forceinline__ f32x16 w3_mfma(const w3_bf16x8& a_hi, const w3_bf16x8& a_lo, const w3_bf16x8& b_hi,
+                                          const w3_bf16x8& b_lo, f32x16 acc) {
+  if (!ABF) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc, 0, 0, 0);
 }
 
 #ifndef W3_SMALL_WPE
@@ -475,7 +493,7 @@ __device__ __forceinline__ void w3_store4(w3_lds_u16* hi_plane, w3_lds_u16* lo_p
 // the 1- and 2-slot 4-wave forms (conv1 16 -> 32 channels: 39 KB of LDS) are pinned to 128 registers so that FOUR
 // workgroups share a CU: 0.753 (three, 136 registers) -> 0.651 ms, 4.9 TB/s (A/B: -DW3_SMALL_WPE=2)
 #define W3_WPE(MAXS, NW) ((MAXS) <= 2 && (NW) == 4 ? W3_SMALL_WPE : 2)
-template <int MAXS, int NW, bool BS>
+template <int MAXS, int NW, bool BS, int ABF>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(W3_WPE(MAXS, NW)))) void wgrad3_kernel(const WgradParams P) {
   constexpr int NTHR = NW * 64;
   const BsedWgradDesc& p = P.d;
@@ -578,7 +596,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(W3_WPE(
         ov[u] = pos * CC + (w3_chunk(c4 >> 3, pc, P.nct) << 5) + 4 * (c4 & 7);
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         okv[u] = e < x_total && gh_ >= 0 && gh_ < p.H && gw >= 0 && gw < p.W && cg < p.CIN;
-        if (okv[u]) v[u] = *reinterpret_cast<const float4*>(inb + ((size_t)gh_ * p.W + gw) * p.in_pitch + cg);
+        if (okv[u]) v[u] = w3_ld4<ABF>(p.in, inb + ((size_t)gh_ * p.W + gw) * p.in_pitch + cg);
       }
 #pragma unroll
       for (int u = 0; u < UX; ++u) {
@@ -588,7 +606,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(W3_WPE(
             v[u].x = fmaf(v[u].x, sc.x, sh.x); v[u].y = fmaf(v[u].y, sc.y, sh.y);
             v[u].z = fmaf(v[u].z, sc.z, sh.z); v[u].w = fmaf(v[u].w, sc.w, sh.w);
           }
-          w3_store4(Xh, Xl, ov[u], v[u]);
+          w3_store4<ABF>(Xh, Xl, ov[u], v[u]);
         }
       }
     }
@@ -604,13 +622,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(W3_WPE(
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e < d_total && gh_ < p.H && gw < p.W && n0 + 4 * n4 < p.N) {
           const size_t o = ((size_t)nb * p.H * p.W + (size_t)gh_ * p.W + gw) * p.dy_pitch + n0 + 4 * n4;
-          v[u] = *reinterpret_cast<const float4*>(p.dy + o);
+          v[u] = w3_ld4<ABF>(p.dy, p.dy + o);
           if (p.bn_y) {
             // BatchNorm backward on load (NTHR is a multiple of n4n: the channel quad is the thread's own, cA/cB/cC)
-            const float4 yv = *reinterpret_cast<const float4*>(p.bn_y + o);
+            const float4 yv = w3_ld4<ABF>(p.bn_y, p.bn_y + o);
             v[u].x = fmaf(cA.x, v[u].x, fmaf(cB.x, yv.x, cC.x)); v[u].y = fmaf(cA.y, v[u].y, fmaf(cB.y, yv.y, cC.y));
             v[u].z = fmaf(cA.z, v[u].z, fmaf(cB.z, yv.z, cC.z)); v[u].w = fmaf(cA.w, v[u].w, fmaf(cB.w, yv.w, cC.w));
-            if (p.dy_out && blockIdx.z == 0) *reinterpret_cast<float4*>(p.dy_out + o) = v[u];
+            if (p.dy_out && blockIdx.z == 0) w3_st4<ABF>(p.dy_out, p.dy_out + o, v[u]);
           }
         }
       }
@@ -618,7 +636,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(W3_WPE(
       for (int u = 0; u < UD; ++u) {
         const int e = e0 + u * NTHR;
         const int n4 = e & (n4n - 1), mm = e >> lgn4;
-        if (e < d_total) w3_store4(DYh, DYl, mm * DYW + (w3_chunk(n4 >> 3, mm, P.ntw) << 5) + 4 * (n4 & 7), v[u]);
+        if (e < d_total) w3_store4<ABF>(DYh, DYl, mm * DYW + (w3_chunk(n4 >> 3, mm, P.ntw) << 5) + 4 * (n4 & 7), v[u]);
       }
     }
     __syncthreads();
@@ -655,9 +673,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(W3_WPE(
             if (sl < MAXS) {
               const w3_bf16x8 b_hi = BS ? bh[0][0] : bh[(g - 1) & 1][BS ? 0 : j];
               const w3_bf16x8 b_lo = BS ? bl[0][0] : bl[(g - 1) & 1][BS ? 0 : j];
-              acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[(g - 1) & 1][j], b_hi, acc[sl], 0, 0, 0);
-              acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[(g - 1) & 1][j], b_lo, acc[sl], 0, 0, 0);
-              acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[(g - 1) & 1][j], b_hi, acc[sl], 0, 0, 0);
+              acc[sl] = w3_mfma<ABF>(ah[(g - 1) & 1][j], al[(g - 1) & 1][j], b_hi, b_lo, acc[sl]);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -708,7 +724,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(W3_WPE(
 
 struct W1Set { float4 x[4], d[4]; };
 
-template <bool SHIFT>
+template <bool SHIFT, int ABF>
 __global__ __launch_bounds__(W1_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad1_kernel(const WgradParams P) {
   const BsedWgradDesc& p = P.d;
   extern __shared__ __align__(16) uint32_t smw[];
@@ -760,8 +776,8 @@ __global__ __launch_bounds__(W1_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         ms = mc + shift;
         ms = ms < 0 ? 0 : (ms >= M ? M - 1 : ms);
       }
-      S.x[u] = *reinterpret_cast<const float4*>(xsrc + (size_t)ms * p.in_pitch);
-      S.d[u] = *reinterpret_cast<const float4*>(dsrc + (size_t)mc * p.dy_pitch);
+      S.x[u] = w3_ld4<ABF>(p.in, xsrc + (size_t)ms * p.in_pitch);
+      S.d[u] = w3_ld4<ABF>(p.dy, dsrc + (size_t)mc * p.dy_pitch);
     }
   };
   auto convert = [&](int tile, const W1Set& S, int stage) {
@@ -782,10 +798,10 @@ __global__ __launch_bounds__(W1_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       float4 v = S.x[u];
       v.x = okx ? fmaf(v.x, sc.x, sh.x) : 0.f; v.y = okx ? fmaf(v.y, sc.y, sh.y) : 0.f;
       v.z = okx ? fmaf(v.z, sc.z, sh.z) : 0.f; v.w = okx ? fmaf(v.w, sc.w, sh.w) : 0.f;
-      w3_store4(xh, xl, so + 16 * u * 128, v);
+      w3_store4<ABF>(xh, xl, so + 16 * u * 128, v);
       float4 g = S.d[u];
       g.x = okd ? g.x : 0.f; g.y = okd ? g.y : 0.f; g.z = okd ? g.z : 0.f; g.w = okd ? g.w : 0.f;
-      w3_store4(dh_, dl, so + 16 * u * 128, g);
+      w3_store4<ABF>(dh_, dl, so + 16 * u * 128, g);
     }
   };
   auto mma = [&](int stage) {
@@ -803,9 +819,7 @@ __global__ __launch_bounds__(W1_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s], acc[s], 0, 0, 0);
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s], acc[s], 0, 0, 0);
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s], acc[s], 0, 0, 0);
+        acc[s] = w3_mfma<ABF>(ah, al, bh[s], bl[s], acc[s]);
       }
     }
   };
@@ -870,7 +884,7 @@ __host__ __device__ constexpr W3Geo w3_geo(int g) {
 }
 #define W3_NGEO 5
 
-template <int MAXS, int GEO>
+template <int MAXS, int GEO, int ABF>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad3p_kernel(const WgradParams P) {
   constexpr int NTHR = 256, NW = 4, UX = W3P_UX, UD = W3P_UD;
   const BsedWgradDesc& p = P.d;
@@ -948,7 +962,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int gh_ = th0 + (xrc[u] >> 16), gw = tw0 + (int)(short)(xrc[u] & 0xffff);
         vx[u] = w3_f32x4{0.f, 0.f, 0.f, 0.f};
         if (gh_ >= 0 && gh_ < p.H && gw >= 0 && gw < p.W) {
-          vx[u] = *reinterpret_cast<const w3_f32x4*>(inb + xg[u]);
+          vx[u] = act_ld4<ABF>(p.in, (size_t)(inb + xg[u] - p.in));
           okx |= 1u << u;
         }
       }
@@ -957,7 +971,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int gh_ = th0 + (drc[u] >> 16), gw = tw0 + (drc[u] & 0xffff);
         vd[u] = w3_f32x4{0.f, 0.f, 0.f, 0.f};
         if (gh_ < p.H && gw < p.W) {
-          vd[u] = *reinterpret_cast<const w3_f32x4*>(dyb + dg[u]);
+          vd[u] = act_ld4<ABF>(p.dy, (size_t)(dyb + dg[u] - p.dy));
           okd |= 1u << u;
         }
       }
@@ -967,7 +981,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int u = 0; u < UD; ++u) {
           vy[u] = w3_f32x4{0.f, 0.f, 0.f, 0.f};
-          if ((okd >> u) & 1) vy[u] = *reinterpret_cast<const w3_f32x4*>(p.bn_y + dy_base + dg[u]);
+          if ((okd >> u) & 1) vy[u] = act_ld4<ABF>(p.bn_y, dy_base + dg[u]);
         }
 #pragma unroll
         for (int u = 0; u < UD; ++u) {
@@ -976,7 +990,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             vd[u][1] = fmaf(cA.y, vd[u][1], fmaf(cB.y, vy[u][1], cC.y));
             vd[u][2] = fmaf(cA.z, vd[u][2], fmaf(cB.z, vy[u][2], cC.z));
             vd[u][3] = fmaf(cA.w, vd[u][3], fmaf(cB.w, vy[u][3], cC.w));
-            if (dy_store) *reinterpret_cast<w3_f32x4*>(p.dy_out + dy_base + dg[u]) = vd[u];
+            if (dy_store) act_st4<ABF>(p.dy_out, dy_base + dg[u], vd[u]);
           }
         }
       }
@@ -990,13 +1004,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
             v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
           }
-          w3_store4(Xh, Xl, bo + xo[u], v);
+          w3_store4<ABF>(Xh, Xl, bo + xo[u], v);
         }
       }
 #pragma unroll
       for (int u = 0; u < UD; ++u)
         if (tid + u * NTHR < d_total)
-          w3_store4(DYh, DYl, bo + dyo[u], make_float4(vd[u][0], vd[u][1], vd[u][2], vd[u][3]));
+          w3_store4<ABF>(DYh, DYl, bo + dyo[u], make_float4(vd[u][0], vd[u][1], vd[u][2], vd[u][3]));
       __syncthreads();
     }
     __syncthreads();  // pairs with the consumers' barrier after their last tile
@@ -1076,9 +1090,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int j = 0; j < SG; ++j) {
               const int sl = (g - 1) * SG + j;
               if (sl < MAXS) {
-                acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[(g - 1) & 1][j], bh, acc[sl], 0, 0, 0);
-                acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[(g - 1) & 1][j], bl, acc[sl], 0, 0, 0);
-                acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[(g - 1) & 1][j], bh, acc[sl], 0, 0, 0);
+                acc[sl] = w3_mfma<ABF>(ah[(g - 1) & 1][j], al[(g - 1) & 1][j], bh, bl, acc[sl]);
               }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1114,9 +1126,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int j = 0; j < SG; ++j) {
               const int sl = (g - 1) * SG + j;
               if (sl < MAXS) {
-                acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[(g - 1) & 1][j], bh, acc[sl], 0, 0, 0);
-                acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[(g - 1) & 1][j], bl, acc[sl], 0, 0, 0);
-                acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[(g - 1) & 1][j], bh, acc[sl], 0, 0, 0);
+                acc[sl] = w3_mfma<ABF>(ah[(g - 1) & 1][j], al[(g - 1) & 1][j], bh, bl, acc[sl]);
               }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1533,9 +1543,14 @@ extern "C" int bsed_wgrad(const BsedWgradDesc* desc, void* stream) {
 
 template <int MAXS, int NW, bool BS>
 static int launch_wgrad3_bs(const WgradParams& P, dim3 grid, size_t smem, hipStream_t s) {
-  static BsedLdsOnce once;
-  BSED_HIP(bsed_max_lds(once, (const void*)wgrad3_kernel<MAXS, NW, BS>));
-  hipLaunchKernelGGL((wgrad3_kernel<MAXS, NW, BS>), grid, dim3(NW * 64), smem, s, P);
+  static BsedLdsOnce once, onceb;
+  if (P.d.act_bf16) {
+    BSED_HIP(bsed_max_lds(onceb, (const void*)wgrad3_kernel<MAXS, NW, BS, 1>));
+    hipLaunchKernelGGL((wgrad3_kernel<MAXS, NW, BS, 1>), grid, dim3(NW * 64), smem, s, P);
+  } else {
+    BSED_HIP(bsed_max_lds(once, (const void*)wgrad3_kernel<MAXS, NW, BS, 0>));
+    hipLaunchKernelGGL((wgrad3_kernel<MAXS, NW, BS, 0>), grid, dim3(NW * 64), smem, s, P);
+  }
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }
@@ -1548,9 +1563,14 @@ static int launch_wgrad3(const WgradParams& P, dim3 grid, size_t smem, hipStream
 
 template <int MAXS, int GEO>
 static int launch_wgrad3p_geo(const WgradParams& P, dim3 grid, size_t smem, hipStream_t s) {
-  static BsedLdsOnce once;
-  BSED_HIP(bsed_max_lds(once, (const void*)wgrad3p_kernel<MAXS, GEO>));
-  hipLaunchKernelGGL((wgrad3p_kernel<MAXS, GEO>), grid, dim3(512), 2 * smem, s, P);
+  static BsedLdsOnce once, onceb;
+  if (P.d.act_bf16) {
+    BSED_HIP(bsed_max_lds(onceb, (const void*)wgrad3p_kernel<MAXS, GEO, 1>));
+    hipLaunchKernelGGL((wgrad3p_kernel<MAXS, GEO, 1>), grid, dim3(512), 2 * smem, s, P);
+  } else {
+    BSED_HIP(bsed_max_lds(once, (const void*)wgrad3p_kernel<MAXS, GEO, 0>));
+    hipLaunchKernelGGL((wgrad3p_kernel<MAXS, GEO, 0>), grid, dim3(512), 2 * smem, s, P);
+  }
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }
@@ -1644,13 +1664,19 @@ extern "C" int bsed_wgrad3(const BsedWgradDesc* desc, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (wgrad1_streaming(P)) {
     const bool shifted = d.dh[0] != 0 || d.dw[0] != 0;
-    static BsedLdsOnce once0, once1;
-    if (shifted) {
-      BSED_HIP(bsed_max_lds(once1, (const void*)wgrad1_kernel<true>));
-      hipLaunchKernelGGL(wgrad1_kernel<true>, grid, dim3(W1_THREADS), 2 * W1_STAGE, s, P);
+    static BsedLdsOnce once0, once1, once0b, once1b;
+    if (d.act_bf16 && shifted) {
+      BSED_HIP(bsed_max_lds(once1b, (const void*)wgrad1_kernel<true, 1>));
+      hipLaunchKernelGGL((wgrad1_kernel<true, 1>), grid, dim3(W1_THREADS), 2 * W1_STAGE, s, P);
+    } else if (d.act_bf16) {
+      BSED_HIP(bsed_max_lds(once0b, (const void*)wgrad1_kernel<false, 1>));
+      hipLaunchKernelGGL((wgrad1_kernel<false, 1>), grid, dim3(W1_THREADS), 2 * W1_STAGE, s, P);
+    } else if (shifted) {
+      BSED_HIP(bsed_max_lds(once1, (const void*)wgrad1_kernel<true, 0>));
+      hipLaunchKernelGGL((wgrad1_kernel<true, 0>), grid, dim3(W1_THREADS), 2 * W1_STAGE, s, P);
     } else {
-      BSED_HIP(bsed_max_lds(once0, (const void*)wgrad1_kernel<false>));
-      hipLaunchKernelGGL(wgrad1_kernel<false>, grid, dim3(W1_THREADS), 2 * W1_STAGE, s, P);
+      BSED_HIP(bsed_max_lds(once0, (const void*)wgrad1_kernel<false, 0>));
+      hipLaunchKernelGGL((wgrad1_kernel<false, 0>), grid, dim3(W1_THREADS), 2 * W1_STAGE, s, P);
     }
     BSED_LAUNCH_CHECK();
     return BSED_OK;

@@ -379,12 +379,14 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PkBatch B
                      // apart = the same banks, a 2-way conflict that a 4-byte store absorbs; 8 KB instead of 10 per workgroup,
                      // which -- with the half-width weight table below -- lets a THIRD workgroup share the CU's LDS)
 
-template <int STATS, int NTAPS, int KS, int NV>
+// ABF = 1 ("bf16" mode): `in` and `out` are bf16 tensors, ONE MFMA per product (the hi halves of the same weight
+// table), patch rows CIN bf16 + 8 pad (48 B / 80 B: odd x 16 B), 16-byte patch pieces of 8 channels
+template <int STATS, int NTAPS, int KS, int NV, int ABF>
 __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params P) {
   constexpr int CINK = 16 * KS;
-  constexpr int I3S_ROW = 2 * CINK + 8;  // ushorts per patch row: CIN hi | CIN lo | 8 pad (80 B / 144 B: odd x 16 B)
-  constexpr int C4 = CINK / 4;           // float4 per patch position
-  constexpr int PV = KS == 1 ? 4 : 6;    // float4 patch elements per thread: 256 x 4 / 192 x 8 patch elements
+  constexpr int I3S_ROW = (ABF ? CINK : 2 * CINK) + 8;  // ushorts per patch row: CIN hi | CIN lo | 8 pad (80 B / 144 B: odd x 16 B)
+  constexpr int C4 = ABF ? CINK / 8 : CINK / 4;   // 16-byte pieces per patch position (4 fp32 / 8 bf16 channels)
+  constexpr int PV = ABF ? (KS == 1 ? 2 : 3) : (KS == 1 ? 4 : 6);    // patch pieces per thread: 256 x 4 / 192 x 8 patch elements
   const BsedIgemmDesc& p = P.d;
   extern __shared__ __align__(16) unsigned short smem3[];
   // NV == 16: output channels 16..31 of the 32-wide MFMA tile do not exist, their weight fragments are never stored:
@@ -422,18 +424,18 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
     ppr[u] = (pos * P.pw_magic) >> 20;
     ppc[u] = pos - ppr[u] * PW;
   }
-  f32x4 pv[PV];
+  u32x4 pv[PV];
   auto issue = [&](int tile) {
     const int tw_i = tile % p.tilesW; const int r1 = tile / p.tilesW;
     const int th_i = r1 % p.tilesH, nb = r1 / p.tilesH;
-    const float* inb = p.in + (size_t)nb * p.H * p.W * p.in_pitch;
+    const char* inb = reinterpret_cast<const char*>(p.in) + (size_t)nb * p.H * p.W * p.in_pitch * (ABF ? 2 : 4);
 #pragma unroll
     for (int u = 0; u < PV; ++u) {
       const int e = tid + u * I3_THREADS;
       const int gh = th_i * p.TH - p.hh + ppr[u], gw = tw_i * p.TW - p.hw + ppc[u];
       const bool ok = e < a_total && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
-      pv[u] = ok ? *reinterpret_cast<const f32x4*>(inb + ((size_t)gh * p.W + gw) * p.in_pitch + 4 * (e % C4))
-                 : f32x4{0.f, 0.f, 0.f, 0.f};
+      pv[u] = ok ? *reinterpret_cast<const u32x4*>(inb + (((size_t)gh * p.W + gw) * p.in_pitch * (ABF ? 2 : 4)) + 16 * (e % C4))
+                 : u32x4{0u, 0u, 0u, 0u};
     }
   };
   if ((int)blockIdx.x < ntiles) issue(blockIdx.x);
@@ -447,12 +449,17 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
     for (int u = 0; u < PV; ++u) {
       const int e = tid + u * I3_THREADS;
       if (e < a_total) {
-        uint32_t h01, l01, h23, l23;
-        bsed_split2(pv[u][0], pv[u][1], h01, l01);
-        bsed_split2(pv[u][2], pv[u][3], h23, l23);
-        unsigned short* dst = As + (e / C4) * I3S_ROW + 4 * (e % C4);
-        *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
-        *reinterpret_cast<uint2*>(dst + CINK) = make_uint2(l01, l23);
+        if (ABF) {
+          *reinterpret_cast<u32x4*>(As + (e / C4) * I3S_ROW + 8 * (e % C4)) = pv[u];
+        } else {
+          uint32_t h01, l01, h23, l23;
+          const f32x4 v = __builtin_bit_cast(f32x4, pv[u]);
+          bsed_split2(v[0], v[1], h01, l01);
+          bsed_split2(v[2], v[3], h23, l23);
+          unsigned short* dst = As + (e / C4) * I3S_ROW + 4 * (e % C4);
+          *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(dst + CINK) = make_uint2(l01, l23);
+        }
       }
     }
     __syncthreads();
@@ -467,14 +474,16 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
 #pragma unroll
       for (int t = 0; t < NTAPS; ++t) {
         a_hi[t] = *reinterpret_cast<const bf16x8*>(As + abase + toff[t] + 16 * kk);
-        a_lo[t] = *reinterpret_cast<const bf16x8*>(As + abase + toff[t] + CINK + 16 * kk);
+        if (!ABF) a_lo[t] = *reinterpret_cast<const bf16x8*>(As + abase + toff[t] + CINK + 16 * kk);
       }
 #pragma unroll
       for (int t = 0; t < NTAPS; ++t) {
         const bf16x8 b_hi = __builtin_bit_cast(bf16x8, Wf[((t * KS + kk) * 2 + 0) * WL + wlane]);
-        const bf16x8 b_lo = __builtin_bit_cast(bf16x8, Wf[((t * KS + kk) * 2 + 1) * WL + wlane]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[t], b_hi, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[t], b_lo, acc, 0, 0, 0);
+        if (!ABF) {
+          const bf16x8 b_lo = __builtin_bit_cast(bf16x8, Wf[((t * KS + kk) * 2 + 1) * WL + wlane]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[t], b_hi, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[t], b_lo, acc, 0, 0, 0);
+        }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[t], b_hi, acc, 0, 0, 0);
       }
     }
@@ -497,7 +506,7 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
         const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
         const f32x4 v = *reinterpret_cast<const f32x4*>(Es + pos * I3S_EROW + 4 * q);
         if (gh < p.H && n0 + 4 * q < p.N)
-          *reinterpret_cast<f32x4*>(p.out + (((size_t)nb * p.H + gh) * p.W + gw) * p.out_pitch + n0 + 4 * q) = v;
+          act_st4<ABF>(p.out, (((size_t)nb * p.H + gh) * p.W + gw) * p.out_pitch + n0 + 4 * q, v);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next tile's image is written
     } else {
@@ -507,7 +516,7 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
         const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
         if (gh < p.H && nok) {
           const float v = acc[r] + bias;
-          p.out[(((size_t)nb * p.H + gh) * p.W + gw) * p.out_pitch + n] = v;
+          act_st<ABF>(p.out, (((size_t)nb * p.H + gh) * p.W + gw) * p.out_pitch + n, v);
           if (STATS) { s0 += v; s1 = fmaf(v, v, s1); }
         }
       }
@@ -641,7 +650,7 @@ extern "C" int bsed_igemm3s(const BsedIgemmDesc* desc, int G, void* stream) {
   BSED_CHECK_ARG(d.ntaps == 9 || d.ntaps == 1, "bsed_igemm3s: 9 or 1 taps");
   for (int t = 0; t < d.ntaps; ++t)
     BSED_CHECK_ARG(abs(d.dh[t]) <= d.hh && abs(d.dw[t]) <= d.hw, "bsed_igemm3s: tap %d outside the halo", t);
-  BSED_CHECK_ARG(d.in_pitch >= d.CIN && d.in_pitch % 4 == 0 && d.out_pitch >= d.N, "bsed_igemm3s: bad pitch");
+  BSED_CHECK_ARG(d.in_pitch >= d.CIN && d.in_pitch % (d.act_bf16 ? 8 : 4) == 0 && d.out_pitch >= d.N, "bsed_igemm3s: bad pitch");
   BSED_CHECK_ARG(d.NP % 32 == 0 && d.NP >= d.N, "bsed_igemm3s: NP must be N rounded up to 32");
   d.tilesH = ceil_div(d.H, d.TH);
   d.tilesW = d.W / d.TW;
@@ -658,16 +667,21 @@ extern "C" int bsed_igemm3s(const BsedIgemmDesc* desc, int G, void* stream) {
   BSED_CHECK_ARG(ntiles < (1L << 31) && G > 0 && G <= ntiles, "bsed_igemm3s: G must be in 1..%ld tiles", ntiles);
   // N <= 16: transposed epilogue (wave-private LDS image, float4 row stores)
   const bool nv16 = d.N <= 16 && d.N % 4 == 0 && d.out_pitch % 4 == 0;
-  const size_t bytes = (size_t)d.ntaps * KS * 2 * (nv16 ? 32 : 64) * 16 + (size_t)P.PP * (2 * d.CIN + 8) * 2 +
+  const size_t bytes = (size_t)d.ntaps * KS * 2 * (nv16 ? 32 : 64) * 16 + (size_t)P.PP * ((d.act_bf16 ? 1 : 2) * d.CIN + 8) * 2 +
                        (nv16 ? (size_t)4 * 32 * I3S_EROW * sizeof(float) : 0);
   dim3 grid((unsigned)G, d.NP / 32);
   hipStream_t s = (hipStream_t)stream;
   const bool st = d.epilogue == BSED_EPI_STATS;
 #define I3S_LAUNCH1(S, T, K, V)                                                                                       \
   do {                                                                                                                \
-    static BsedLdsOnce once;                                                                                         \
-    BSED_HIP(bsed_max_lds(once, (const void*)igemm3s_kernel<S, T, K, V>));                                                                                                                 \
-    hipLaunchKernelGGL((igemm3s_kernel<S, T, K, V>), grid, dim3(I3_THREADS), bytes, s, P);                            \
+    static BsedLdsOnce once, onceb;                                                                                   \
+    if (d.act_bf16) {                                                                                                 \
+      BSED_HIP(bsed_max_lds(onceb, (const void*)igemm3s_kernel<S, T, K, V, 1>));                                     \
+      hipLaunchKernelGGL((igemm3s_kernel<S, T, K, V, 1>), grid, dim3(I3_THREADS), bytes, s, P);                       \
+    } else {                                                                                                          \
+      BSED_HIP(bsed_max_lds(once, (const void*)igemm3s_kernel<S, T, K, V, 0>));                                      \
+      hipLaunchKernelGGL((igemm3s_kernel<S, T, K, V, 0>), grid, dim3(I3_THREADS), bytes, s, P);                       \
+    }                                                                                                                 \
   } while (0)
 #define I3S_LAUNCH(T, K)                                                                                              \
   do {                                                                                                                \

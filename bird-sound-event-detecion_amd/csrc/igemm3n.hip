@@ -59,10 +59,16 @@ __device__ __forceinline__ int crow3n(int r, int lh) { return (r & 3) + 8 * (r >
 // two row blocks, 32 accumulator registers, four waves per SIMD; measured slower -- twice the weight-fragment loads --
 // and not instantiated).  P.prio: raised wave priority outside the MFMA loop (prologue and epilogue are issue-bound
 // beside two waves that multiply: 1-3 % on the PV = 9 layers).
-template <int NWN, int MW, int STATS, int PV, int NT9, int WPE>
+// ABF = 1: the "bf16" throughput mode (BASELINE configs[1-2]): input AND output activations are bf16 in HBM, ONE bf16
+// MFMA per product (the hi halves of the same weight table), fp32 accumulation, bias and BatchNorm sums; the patch
+// goes to LDS as it arrives (rows of 32 bf16 + 8 pad = 80 B: 20 r mod 64 hits 16 distinct 4-bank groups).
+template <int NWN, int MW, int STATS, int PV, int NT9, int WPE, int ABF>
 __global__ __launch_bounds__(64 * NWN * MW) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void igemm3n_kernel(const Igemm3nParams P) {
   constexpr int RB = 4 / MW, NTH = 64 * NWN * MW;
+  constexpr int ROW = ABF ? 40 : I3N_ROW;      // ushorts per LDS patch row
+  constexpr int LGP = ABF ? 2 : 3;             // log2 of 16-byte pieces per patch position (8 bf16 / 4 fp32 channels each)
+  constexpr int NF = ABF ? 2 : 4;              // weight fragments per step
   const bool PRIO = P.prio != 0;
   if (PRIO) __builtin_amdgcn_s_setprio(3);
   const BsedIgemmDesc& p = P.d;
@@ -100,7 +106,7 @@ void igemm3n_kernel(const Igemm3nParams P) {
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const int m = (wm * RB + rb) * 32 + li;
-    abase[rb] = (((m >> P.lgTW) + p.hh) * PW + (m & (p.TW - 1)) + p.hw) * I3N_ROW + 8 * lh;
+    abase[rb] = (((m >> P.lgTW) + p.hh) * PW + (m & (p.TW - 1)) + p.hw) * ROW + 8 * lh;
   }
   f32x16 acc[RB];
 #pragma unroll
@@ -108,23 +114,26 @@ void igemm3n_kernel(const Igemm3nParams P) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
 
-  const float* inb = p.in + (size_t)nb * p.H * p.W * p.in_pitch;
+  // 16-byte units of the input image: 4 fp32 / 8 bf16 channels; poff counts them
+  const u32x4* inb = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.in) +
+                                                    (size_t)nb * p.H * p.W * p.in_pitch * (ABF ? 2 : 4));
   const int nchunks = p.CIN / I3N_KC, KS = 2 * nchunks, ntaps = NT9 ? 9 : p.ntaps;
-  const int a_total = P.PP * (I3N_KC / 4);
-  f32x4 pv[PV];
+  const int a_total = P.PP << LGP;
+  const int pitch16 = p.in_pitch >> (ABF ? 3 : 2), chunk16 = 1 << LGP;   // 16-byte units per position / per chunk
+  u32x4 pv[PV];
   int poff[PV];
 #pragma unroll
   for (int u = 0; u < PV; ++u) {
     const int e = tid + u * NTH;
-    const int c4 = e & 7, pos = e >> 3;
+    const int c4 = e & (chunk16 - 1), pos = e >> LGP;
     const int pr = (pos * P.pw_magic) >> 20, pc = pos - pr * PW;
     const int gh = th0 - p.hh + pr, gw = tw0 - p.hw + pc;
-    poff[u] = (e < a_total && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) ? (gh * p.W + gw) * p.in_pitch + 4 * c4 : -1;
+    poff[u] = (e < a_total && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) ? (gh * p.W + gw) * pitch16 + c4 : -1;
   }
   // branch-free loads (a divergent branch around a load turns every later counted wait into vmcnt(0)): padding
   // positions read the image's first element and are zeroed when the patch is written to LDS
 #pragma unroll
-  for (int u = 0; u < PV; ++u) pv[u] = *reinterpret_cast<const f32x4*>(inb + max(poff[u], 0));
+  for (int u = 0; u < PV; ++u) pv[u] = inb[max(poff[u], 0)];
 
   // bias of this lane's channel: requested here so that the epilogue never waits for it
   const int n = n0 + 32 * wn + li;
@@ -133,21 +142,26 @@ void igemm3n_kernel(const Igemm3nParams P) {
 
   // this wave's weight fragments: table[jn][tap][k16][hi|lo][lane] of 16-byte elements (bsed_pack_weight3s layout)
   const u32x4* wb = reinterpret_cast<const u32x4*>(p.w) + ((size_t)(n0 / 32 + wn) * ntaps * KS) * 128 + lane;
-  u32x4 bq[4];   // the current step's fragments: [k half][hi | lo]
+  u32x4 bq[NF];   // the current step's fragments: [k half][hi | lo]  (ABF: [k half], hi only)
 #pragma unroll
-  for (int f = 0; f < 4; ++f) bq[f] = wb[f * 64];
+  for (int f = 0; f < NF; ++f) bq[f] = wb[(ABF ? 2 * f : f) * 64];
 
   // piece u of the prefetched patch chunk -> LDS (split into bf16 hi / lo; padding positions become zeros)
   auto write_piece = [&](int u, unsigned short* dstbuf) {
     const int e = tid + u * NTH;
     if (e < a_total) {
-      uint32_t h01, l01, h23, l23;
-      const f32x4 v = poff[u] >= 0 ? pv[u] : f32x4{0.f, 0.f, 0.f, 0.f};
-      bsed_split2(v[0], v[1], h01, l01);
-      bsed_split2(v[2], v[3], h23, l23);
-      unsigned short* dst = dstbuf + (e >> 3) * I3N_ROW + 4 * (e & 7);
-      *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
-      *reinterpret_cast<uint2*>(dst + 32) = make_uint2(l01, l23);
+      if (ABF) {
+        const u32x4 v = poff[u] >= 0 ? pv[u] : u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(dstbuf + (e >> 2) * ROW + 8 * (e & 3)) = v;
+      } else {
+        uint32_t h01, l01, h23, l23;
+        const f32x4 v = poff[u] >= 0 ? __builtin_bit_cast(f32x4, pv[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bsed_split2(v[0], v[1], h01, l01);
+        bsed_split2(v[2], v[3], h23, l23);
+        unsigned short* dst = dstbuf + (e >> 3) * ROW + 4 * (e & 7);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(dst + 32) = make_uint2(l01, l23);
+      }
     }
   };
   // NT9: the patch of chunk ch + 1 is written into the OTHER buffer during the taps of chunk ch (one piece per tap
@@ -175,7 +189,7 @@ void igemm3n_kernel(const Igemm3nParams P) {
     if (PRIO && ch == 0) __builtin_amdgcn_s_setprio(0);
     if (!EARLYW && more) {
 #pragma unroll
-      for (int u = 0; u < PV; ++u) pv[u] = *reinterpret_cast<const f32x4*>(inb + max(poff[u], 0) + (ch + 1) * I3N_KC);
+      for (int u = 0; u < PV; ++u) pv[u] = inb[max(poff[u], 0) + (ch + 1) * chunk16];
     }
     auto step = [&](int tap) {
       // next step's fragments (the very last step re-reads its own: no branch around the loads)
@@ -183,9 +197,9 @@ void igemm3n_kernel(const Igemm3nParams P) {
       if (ntap == ntaps) { ntap = 0; nch = ch + 1; }
       if (!more && nch != ch) { ntap = tap; nch = ch; }
       const u32x4* wn_ = wb + (size_t)(ntap * KS + 2 * nch) * 128;
-      u32x4 bn[4];
+      u32x4 bn[NF];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) bn[f] = wn_[f * 64];
+      for (int f = 0; f < NF; ++f) bn[f] = wn_[(ABF ? 2 * f : f) * 64];
       // (hipcc sinks these loads to just before their first use -- a step later -- to save registers, which exposes
       //  the L2 latency twice per step; the scheduling fence below keeps them ahead of this step's reads and MFMAs)
       if (EARLYW && more) {
@@ -193,7 +207,7 @@ void igemm3n_kernel(const Igemm3nParams P) {
         // half the pieces are in registers at a time
 #pragma unroll
         for (int u = 0; u < PV; ++u)
-          if (tap == (6 * u) / PV) pv[u] = *reinterpret_cast<const f32x4*>(inb + max(poff[u], 0) + (ch + 1) * I3N_KC);
+          if (tap == (6 * u) / PV) pv[u] = inb[max(poff[u], 0) + (ch + 1) * chunk16];
       }
       __builtin_amdgcn_sched_barrier(0);
       if (EARLYW && more) {
@@ -201,25 +215,28 @@ void igemm3n_kernel(const Igemm3nParams P) {
         for (int u = 0; u < PV; ++u)
           if (tap == (6 * u) / PV + 3) write_piece(u, An);
       }
-      const int toff = (p.dh[tap] * PW + p.dw[tap]) * I3N_ROW;
+      const int toff = (p.dh[tap] * PW + p.dw[tap]) * ROW;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8 a_hi[RB], a_lo[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
           a_hi[rb] = *reinterpret_cast<const bf16x8*>(As + abase[rb] + toff + 16 * kk);
-          a_lo[rb] = *reinterpret_cast<const bf16x8*>(As + abase[rb] + toff + 32 + 16 * kk);
+          if (!ABF) a_lo[rb] = *reinterpret_cast<const bf16x8*>(As + abase[rb] + toff + 32 + 16 * kk);
         }
-        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, bq[2 * kk]), b_lo = __builtin_bit_cast(bf16x8, bq[2 * kk + 1]);
+        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, bq[ABF ? kk : 2 * kk]);
+        if (!ABF) {
+          const bf16x8 b_lo = __builtin_bit_cast(bf16x8, bq[ABF ? kk : 2 * kk + 1]);
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[rb], b_hi, acc[rb], 0, 0, 0);
+          for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[rb], b_hi, acc[rb], 0, 0, 0);
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[rb], b_lo, acc[rb], 0, 0, 0);
+          for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[rb], b_lo, acc[rb], 0, 0, 0);
+        }
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[rb], b_hi, acc[rb], 0, 0, 0);
       }
 #pragma unroll
-      for (int f = 0; f < 4; ++f) bq[f] = bn[f];
+      for (int f = 0; f < NF; ++f) bq[f] = bn[f];
     };
     if (NT9) {
 #pragma unroll
@@ -244,8 +261,13 @@ void igemm3n_kernel(const Igemm3nParams P) {
   // its (row, column) in the tile -- and with it the element offset -- is the SUM of the three parts' offsets:
   // a scalar base per store (SALU), ONE per-lane byte offset for all 16 RB stores, no vector address arithmetic
   auto eoff = [&](int m) { return ((m >> P.lgTW) * p.W + (m & (p.TW - 1))) * p.out_pitch; };
-  char* ob = reinterpret_cast<char*>(p.out + (((size_t)nb * p.H + th0) * p.W + tw0) * p.out_pitch);
-  const uint32_t voff = (uint32_t)(eoff(4 * lh) + n) * 4u;
+  constexpr uint32_t OSZ = ABF ? 2u : 4u;   // bytes per output element
+  char* ob = reinterpret_cast<char*>(p.out) + (((size_t)nb * p.H + th0) * p.W + tw0) * p.out_pitch * OSZ;
+  const uint32_t voff = (uint32_t)(eoff(4 * lh) + n) * OSZ;
+  auto put = [&](char* dst, float v) {
+    if (ABF) *reinterpret_cast<__bf16*>(dst) = (__bf16)v;   // round to nearest even (v_cvt_pk_bf16_f32)
+    else *reinterpret_cast<float*>(dst) = v;
+  };
   float s0 = 0.f, s1 = 0.f;
   if (full) {
 #pragma unroll
@@ -255,8 +277,8 @@ void igemm3n_kernel(const Igemm3nParams P) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float v = acc[rb][4 * rg + q] + bias;
-          char* sb = ob + (size_t)(uint32_t)(eoff((wm * RB + rb) * 32 + 8 * rg) + eoff(q)) * 4u;
-          *reinterpret_cast<float*>(sb + voff) = v;
+          char* sb = ob + (size_t)(uint32_t)(eoff((wm * RB + rb) * 32 + 8 * rg) + eoff(q)) * OSZ;
+          put(sb + voff, v);
           if (STATS) { s0 += v; s1 = fmaf(v, v, s1); }
         }
   } else {
@@ -270,8 +292,8 @@ void igemm3n_kernel(const Igemm3nParams P) {
         for (int q = 0; q < 4; ++q) {
           const float v = acc[rb][4 * rg + q] + bias;
           if (nok && th0 + dr0 + (q >> P.lgTW) < vh && tw0 + dc0 + (q & (p.TW - 1)) < vw) {
-            char* sb = ob + (size_t)(uint32_t)(eoff((wm * RB + rb) * 32 + 8 * rg) + eoff(q)) * 4u;
-            *reinterpret_cast<float*>(sb + voff) = v;
+            char* sb = ob + (size_t)(uint32_t)(eoff((wm * RB + rb) * 32 + 8 * rg) + eoff(q)) * OSZ;
+            put(sb + voff, v);
             if (STATS) { s0 += v; s1 = fmaf(v, v, s1); }
           }
         }
@@ -294,11 +316,11 @@ void igemm3n_kernel(const Igemm3nParams P) {
 #endif
 }
 
-template <int NWN, int MW, int STATS, int PV, int NT9, int WPE>
+template <int NWN, int MW, int STATS, int PV, int NT9, int WPE, int ABF = 0>
 static int launch_i3n6(const Igemm3nParams& P, dim3 grid, size_t smem, hipStream_t s) {
   static BsedLdsOnce once;
-  BSED_HIP(bsed_max_lds(once, (const void*)igemm3n_kernel<NWN, MW, STATS, PV, NT9, WPE>));
-  hipLaunchKernelGGL((igemm3n_kernel<NWN, MW, STATS, PV, NT9, WPE>), grid, dim3(64 * NWN * MW), smem, s, P);
+  BSED_HIP(bsed_max_lds(once, (const void*)igemm3n_kernel<NWN, MW, STATS, PV, NT9, WPE, ABF>));
+  hipLaunchKernelGGL((igemm3n_kernel<NWN, MW, STATS, PV, NT9, WPE, ABF>), grid, dim3(64 * NWN * MW), smem, s, P);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }
@@ -318,10 +340,15 @@ static int i3n_knob() {
 
 // which build runs a (BN, patch size, taps) combination (PV = 0: unsupported patch size)
 struct I3nPlan { int NWN, MW, PV, WPE; };
-static I3nPlan i3n_plan(int NP, int PP, int ntaps) {
+static I3nPlan i3n_plan(int NP, int PP, int ntaps, int abf) {
   const int NWN = NP % 128 == 0 ? 4 : (NP % 64 == 0 ? 2 : 1);
   const int wpe = i3n_knob() & 7;
   I3nPlan pl{NWN, 4 / NWN, 0, 3};
+  if (abf) {   // bf16 activations: 16-byte pieces of 8 channels, half the registers: three waves per SIMD throughout
+    const int need = ceil_div(PP * 4, 256);
+    pl.PV = need <= 3 ? 3 : (need <= 5 ? 5 : 0);
+    return pl;
+  }
   const int need = ceil_div(PP * 8, 256);
   pl.PV = need <= 6 ? 6 : (need <= 9 ? 9 : 0);
   // BN = 128: three waves per SIMD (168 registers) only for the shape that fits them without spilling in the loop
@@ -331,36 +358,41 @@ static I3nPlan i3n_plan(int NP, int PP, int ntaps) {
   return pl;
 }
 
-template <int NWN, int STATS, int PV, int WPE>
+template <int NWN, int STATS, int PV, int WPE, int ABF = 0>
 static int launch_i3n4(const Igemm3nParams& P, dim3 grid, size_t smem, hipStream_t s) {
-  return P.d.ntaps == 9 ? launch_i3n6<NWN, 4 / NWN, STATS, PV, 1, WPE>(P, grid, smem, s)
-                        : launch_i3n6<NWN, 4 / NWN, STATS, PV, 0, WPE>(P, grid, smem, s);
+  return P.d.ntaps == 9 ? launch_i3n6<NWN, 4 / NWN, STATS, PV, 1, WPE, ABF>(P, grid, smem, s)
+                        : launch_i3n6<NWN, 4 / NWN, STATS, PV, 0, WPE, ABF>(P, grid, smem, s);
 }
 
 template <int NWN, int STATS>
 static int launch_i3n(const Igemm3nParams& P, dim3 grid, size_t smem, hipStream_t s) {
-  const I3nPlan pl = i3n_plan(P.d.NP, P.PP, P.d.ntaps);
-  if (NWN == 4 && pl.PV == 6 && pl.WPE == 3) return launch_i3n4<NWN, STATS, 6, 3>(P, grid, smem, s);
-  if (NWN == 4 && pl.PV == 9 && pl.WPE == 3) return launch_i3n4<NWN, STATS, 9, 3>(P, grid, smem, s);
-  if (NWN == 4 && pl.PV == 6) return launch_i3n4<NWN, STATS, 6, 2>(P, grid, smem, s);
-  if (NWN == 4 && pl.PV == 9) return launch_i3n4<NWN, STATS, 9, 2>(P, grid, smem, s);
-  if (NWN != 4 && pl.PV == 6) return launch_i3n4<NWN, STATS, 6, 3>(P, grid, smem, s);
-  if (NWN != 4 && pl.PV == 9) return launch_i3n4<NWN, STATS, 9, 3>(P, grid, smem, s);
+  const I3nPlan pl = i3n_plan(P.d.NP, P.PP, P.d.ntaps, P.d.act_bf16);
+  if (P.d.act_bf16) {
+    if (pl.PV == 3) return launch_i3n4<NWN, STATS, 3, 3, 1>(P, grid, smem, s);
+    if (pl.PV == 5) return launch_i3n4<NWN, STATS, 5, 3, 1>(P, grid, smem, s);
+  } else {
+    if (NWN == 4 && pl.PV == 6 && pl.WPE == 3) return launch_i3n4<NWN, STATS, 6, 3>(P, grid, smem, s);
+    if (NWN == 4 && pl.PV == 9 && pl.WPE == 3) return launch_i3n4<NWN, STATS, 9, 3>(P, grid, smem, s);
+    if (NWN == 4 && pl.PV == 6) return launch_i3n4<NWN, STATS, 6, 2>(P, grid, smem, s);
+    if (NWN == 4 && pl.PV == 9) return launch_i3n4<NWN, STATS, 9, 2>(P, grid, smem, s);
+    if (NWN != 4 && pl.PV == 6) return launch_i3n4<NWN, STATS, 6, 3>(P, grid, smem, s);
+    if (NWN != 4 && pl.PV == 9) return launch_i3n4<NWN, STATS, 9, 3>(P, grid, smem, s);
+  }
   bsed_set_error("bsed_igemm3n: patch of %d positions exceeds the 288 this build stages", P.PP);
   return BSED_ERR_ARG;
 }
 
-// NWN | MW << 4 | PV << 8 | WPE << 12 of the build bsed_igemm3n would launch (kernel labels of bench.py)
+// NWN | MW << 4 | PV << 8 | WPE << 12 | ABF << 16 of the build bsed_igemm3n would launch (kernel labels of bench.py)
 extern "C" int bsed_igemm3n_variant(const BsedIgemmDesc* d) {
   if (!d || d->TH <= 0 || d->TW <= 0) return -1;
   const int PP = (d->TW + 2 * d->hw) * (d->TH + 2 * d->hh);
-  const I3nPlan pl = i3n_plan(d->NP, PP, d->ntaps);
-  return pl.NWN | pl.MW << 4 | pl.PV << 8 | pl.WPE << 12;
+  const I3nPlan pl = i3n_plan(d->NP, PP, d->ntaps, d->act_bf16);
+  return pl.NWN | pl.MW << 4 | pl.PV << 8 | pl.WPE << 12 | (d->act_bf16 ? 1 : 0) << 16;
 }
 
 extern "C" int bsed_igemm3n_stats_rows(const BsedIgemmDesc* d) {
   if (!d || d->TH <= 0 || d->TW <= 0) return -1;
-  const I3nPlan pl = i3n_plan(d->NP, (d->TW + 2 * d->hw) * (d->TH + 2 * d->hh), d->ntaps);
+  const I3nPlan pl = i3n_plan(d->NP, (d->TW + 2 * d->hw) * (d->TH + 2 * d->hh), d->ntaps, d->act_bf16);
   return d->NB * ceil_div(d->H, d->TH) * (d->W / d->TW) * pl.MW;
 }
 
@@ -380,7 +412,7 @@ extern "C" int bsed_igemm3n(const BsedIgemmDesc* desc, void* stream) {
   BSED_CHECK_ARG(d.ntaps >= 1 && d.ntaps <= 9, "bsed_igemm3n: ntaps must be in 1..9");
   for (int t = 0; t < d.ntaps; ++t)
     BSED_CHECK_ARG(abs(d.dh[t]) <= d.hh && abs(d.dw[t]) <= d.hw, "bsed_igemm3n: tap %d outside the halo", t);
-  BSED_CHECK_ARG(d.in_pitch >= d.CIN && d.in_pitch % 4 == 0 && d.out_pitch >= d.N, "bsed_igemm3n: bad pitch");
+  BSED_CHECK_ARG(d.in_pitch >= d.CIN && d.in_pitch % (d.act_bf16 ? 8 : 4) == 0 && d.out_pitch >= d.N, "bsed_igemm3n: bad pitch");
   BSED_CHECK_ARG(d.NP % 32 == 0 && d.NP >= d.N, "bsed_igemm3n: NP must be N rounded up to 32");
   const int BN = d.NP % 128 == 0 ? 128 : (d.NP % 64 == 0 ? 64 : 32);
   d.tilesH = ceil_div(d.H, d.TH);
@@ -388,7 +420,7 @@ extern "C" int bsed_igemm3n(const BsedIgemmDesc* desc, void* stream) {
   P.PW = d.TW + 2 * d.hw;
   P.PH = d.TH + 2 * d.hh;
   P.PP = P.PW * P.PH;
-  P.b_off = (P.PP * I3N_ROW + 7) & ~7;
+  P.b_off = (P.PP * (d.act_bf16 ? 40 : I3N_ROW) + 7) & ~7;
   P.prio = (i3n_knob() & 8) ? 0 : 1;
   P.pw_magic = ((1 << 20) + P.PW - 1) / P.PW;
   for (int pos = 0; pos < P.PP; ++pos)

@@ -189,9 +189,15 @@ class CRNN(_FlatModule):
         # bf16 matrix cores with split-fp32 operands (csrc/igemm3.hip; measured 5.5e-6 on the logits of the reference
         # config, 18x inside the 1e-4 bar).  "fp32": exact fp32 matrix cores everywhere (9.6e-7 on the logits).
         import os as _os
+        # "bf16" (BASELINE configs[1-2], SURVEY.md section 0 D4 / 8(d): the THROUGHPUT mode, not the parity mode): the CNN's
+        # activations -- conv outputs, pooled outputs and every gradient tensor of the same shapes -- are bf16 in HBM and
+        # its contractions are ONE bf16 MFMA per product; accumulation, bias, BatchNorm statistics and their backward map,
+        # GLU gate math, master weights, weight gradients and the optimizer stay fp32.  The GRU and the head keep fp32
+        # tensors and split-fp32 contractions (their tensors are 2 % of the step's bytes).  tests/test_bf16_mode_gpu.py
+        # states its tolerance against the fp32 oracle.
         self.conv_mode = _os.environ.get("BSED_CONV_MODE", "bf16x3")
-        if self.conv_mode not in ("fp32", "bf16x3"):
-            raise L.BsedError(f"BSED_CONV_MODE must be fp32 or bf16x3, got {self.conv_mode!r}")
+        if self.conv_mode not in ("fp32", "bf16x3", "bf16"):
+            raise L.BsedError(f"BSED_CONV_MODE must be fp32, bf16x3 or bf16, got {self.conv_mode!r}")
         pspecs, bspecs = [], []
         cin = 1
         for i, co in enumerate(nb_filters):
@@ -264,6 +270,27 @@ class CRNN(_FlatModule):
     def set_seed(self, seed):
         self.seed = int(seed)
 
+    @property
+    def _rnn_mode(self):
+        return "fp32" if self.conv_mode == "fp32" else "bf16x3"
+
+    @property
+    def _mfma3(self):
+        """contractions on the bf16 matrix cores (split-fp32 operands, or single bf16 products in the bf16 mode)"""
+        return self.conv_mode in ("bf16x3", "bf16")
+
+    @property
+    def act_dtype(self):
+        """storage type of the CNN's activation / gradient tensors"""
+        return torch.bfloat16 if self.conv_mode == "bf16" else torch.float32
+
+    def _check_bf16_mode(self):
+        if self.conv_mode == "bf16" and not (ops.igemm3_nsplit() and self.glu3 and self.block0_fused and self.fused_glu_bwd
+                                             and not any(c.__name__ == "CRNN_fpn" for c in type(self).__mro__)
+                                             and self.nb_filters[0] == 16 and all(f >= 32 for f in self.nb_filters[1:])):
+            raise L.BsedError("conv_mode='bf16' is built for the plain CRNN / CRNN_pred path (fused first block with 16 "
+                              "filters, N-split conv kernel, bf16-core GLU kernels); FPN variant and A/B switches: use bf16x3")
+
     def load_state_dict(self, state_dict, strict=True):
         # reference checkpoints carry "cnn.conv0.weight"; its loaders rewrite to "cnn.cnn." (save_features.py:48-52)
         sd = OrderedDict((k.replace("cnn.cnn.", "cnn.", 1) if k.startswith("cnn.cnn.") else k, v)
@@ -310,14 +337,16 @@ class CRNN(_FlatModule):
         taps, wsrc, s_tap = self._conv_taps(cw, Ww)
         if first and co == 16 and self.block0_fused and 1 < Ww <= 256 and B * Hh * Ww < (1 << 31):
             return self._block0_forward(a, B, Hh, Ww, pool, names, drop, rng_stream, nbt, train, bn_pre)
+        if self.conv_mode == "bf16" and (first or a.dtype != torch.bfloat16):
+            raise L.BsedError("conv_mode='bf16': this block has no bf16 path (first block must be the fused 16-filter one)")
         if first:
             y, stats = ops.conv0_fwd(a, cw, cb, B, Hh, Ww, co, want_stats=train)
         else:
             epi = ops.EPI_STATS if train else ops.EPI_PLAIN
-            if self.conv_mode == "bf16x3" and cin % 32 == 0:
+            if self._mfma3 and cin % 32 == 0:
                 w3 = ops.pack_weight3(wsrc, len(taps), cin, co, s_tap, 9, cin * 9)
                 y, stats = ops.igemm3(a, w3, co, B, Hh, Ww, cin, taps, bias=cb, epilogue=epi)
-            elif self.conv_mode == "bf16x3" and cin == 16 and ops.igemm3s_supported(Ww, cin):
+            elif self._mfma3 and cin == 16 and ops.igemm3s_supported(Ww, cin):
                 w3s = ops.pack_weight3s(cw, 9, co, 1, 9, cin * 9)
                 y, stats = ops.igemm3s(a, w3s, co, B, Hh, Ww, ops.TAPS3x3, bias=cb, epilogue=epi)
             else:
@@ -335,7 +364,7 @@ class CRNN(_FlatModule):
             # 4 FLOP/B: HBM-bound streaming kernel instead of the MFMA tile kernel (csrc/glu_small.hip)
             pooled = ops.glu16_fwd(y, scale, shift, glu.weight, glu.bias, B, Hh, Ww, (ph, pw), drop, rng_stream,
                                    self.seed)
-        elif self.conv_mode == "bf16x3" and self.glu3 and ops.glu_fwd3_supported(Ww, co, (ph, pw)):
+        elif self._mfma3 and self.glu3 and ops.glu_fwd3_supported(Ww, co, (ph, pw)):
             pooled = ops.glu_fwd3(y, scale, shift, glu.weight, glu.bias, B, Hh, Ww, co, (ph, pw), drop, rng_stream,
                                   self.seed)
         else:
@@ -361,7 +390,7 @@ class CRNN(_FlatModule):
             mean = invstd = None
             scale, shift = bn_pre or ops.bn_eval(16, BN_EPS, bn.weight, bn.bias, bn.running_mean, bn.running_var)
         pooled = ops.block0_fwd(a, cw, cb, scale, shift, glu.weight, glu.bias, B, Hh, Ww, pool, drop, rng_stream,
-                                self.seed)
+                                self.seed, out_dtype=self.act_dtype)
         blk = dict(inp=a, y=None, xr64=xr64, mean=mean, invstd=invstd, scale=scale, shift=shift, H=Hh, W=Ww, cin=1,
                    co=16, pool=pool, names=names, drop=drop, rng=rng_stream, first=True)
         return pooled, blk
@@ -379,7 +408,7 @@ class CRNN(_FlatModule):
         layers = []
         for l in range(2):
             nin, w_ih, w_hh, b_ih, b_hh = self._rnn_views(l, prefix)
-            if self.conv_mode == "bf16x3":
+            if self._mfma3:
                 w3 = ops.pack_weight3(w_ih, 1, nin, 768, 0, 1, nin)
                 xp, _ = ops.igemm3(seq, w3, 768, 1, B * T, 1, nin, ((0, 0),), bias=b_ih)
             else:
@@ -390,7 +419,7 @@ class CRNN(_FlatModule):
                 # the next batch's mel transform on its feature stream here)
                 hook, self.rnn_hook = self.rnn_hook, None
                 hook()
-            out, gates = ops.gru_fwd(xp.view(B, T, 768), w_hh, b_hh, B, T, save_gates=save, mode=self.conv_mode)
+            out, gates = ops.gru_fwd(xp.view(B, T, 768), w_hh, b_hh, B, T, save_gates=save, mode=self._rnn_mode)
             layers.append(dict(inp=seq, out=out, gates=gates))
             seq = out
         return seq, layers
@@ -430,7 +459,7 @@ class CRNN(_FlatModule):
         for l in (1, 0):
             nin, w_ih, w_hh, b_ih, b_hh = self._rnn_views(l, prefix)
             lay = layers[l]
-            dxp, dgh, pih, phh = ops.gru_bwd(d, lay["out"], lay["gates"], w_hh, B, T, mode=self.conv_mode)
+            dxp, dgh, pih, phh = ops.gru_bwd(d, lay["out"], lay["gates"], w_hh, B, T, mode=self._rnn_mode)
             if self.overlap_rnn:
                 main, side = torch.cuda.current_stream(), self._side()
                 side.wait_stream(main)                      # dxp / dgh (and the zeroed gradient arena) are ready
@@ -441,7 +470,7 @@ class CRNN(_FlatModule):
                         t.record_stream(side)               # the allocator must not recycle them under the side stream
             else:
                 self._gru_param_grads(lay, l, prefix, dxp, dgh, pih, phh, B, T)
-            if self.conv_mode == "bf16x3":
+            if self._mfma3:
                 w3 = ops.pack_weight3(w_ih, 1, 768, nin, 0, nin, 1)
                 d, _ = ops.igemm3(dxp, w3, nin, 1, B * T, 1, 768, ((0, 0),))
             else:
@@ -476,13 +505,13 @@ class CRNN(_FlatModule):
                                                 dpool.contiguous(), B, Hh, Ww, (ph, pw), drop_b, rng, seed)
             ops.reduce_partials(pdw, G, 1, 16, 16, 16, 16, glu.weight.grad, 0, 16, 1)
             ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
-        elif co in (32, 64) and self.fused_glu_bwd and self.conv_mode == "bf16x3" and self.glu3:
+        elif co in (32, 64) and self.fused_glu_bwd and self._mfma3 and self.glu3:
             # all three contractions on the bf16 cores, operands fetched in MFMA register layout (csrc/glu3.hip)
             g, pdw, pdb, st2, G, slabs = ops.glu_bwd3(y, blk["scale"], blk["shift"], glu.weight, glu.bias,
                                                       dpool.contiguous(), B, Hh, Ww, co, (ph, pw), drop_b, rng, seed)
             ops.reduce_partials(pdw, G * slabs, 1, co, co, co, co, glu.weight.grad, 0, co, 1)
             ops.stats_to_grad(pdb, co, 0, glu.bias.grad)
-        elif co == 128 and self.fused_glu_bwd and self.conv_mode == "bf16x3" and self.glu3:
+        elif co == 128 and self.fused_glu_bwd and self._mfma3 and self.glu3:
             # lin recompute + g on the bf16 cores; d_lin goes through HBM to a 1-tap weight-gradient contraction
             g, dlin, pdb, st2, G = ops.glu_bwd3n(y, blk["scale"], blk["shift"], glu.weight, glu.bias,
                                                  dpool.contiguous(), B, Hh, Ww, co, (ph, pw), drop_b, rng, seed)
@@ -524,7 +553,7 @@ class CRNN(_FlatModule):
             ops.reduce_partials(part, G, 9, 1, co, 1, co, cw.grad, 1, 9, 9)
             return None
         taps, wsrc, s_tap = self._conv_taps(cw, Ww)
-        if self.conv_mode == "bf16x3":
+        if self._mfma3:
             # (4) BatchNorm backward applied on load inside the weight-gradient kernel (d_y = A g + B (y - mean) + C),
             # which also writes d_y once for the data gradient: the separate apply pass over g and y is gone
             coef = ops.bn_bwd(st2, co, float(B * Hh * Ww), bn.weight, blk["mean"], blk["invstd"], bn.weight.grad,
@@ -543,11 +572,11 @@ class CRNN(_FlatModule):
         if not need_dgrad:
             return None
         flipped = [(-a, -b) for a, b in taps]
-        if self.conv_mode == "bf16x3" and co == 32 and cin <= 32 and ops.igemm3s_supported(Ww, co):
+        if self._mfma3 and co == 32 and cin <= 32 and ops.igemm3s_supported(Ww, co):
             # data gradient of a 32-channel layer: all taps' weights resident in LDS (csrc/igemm3.hip, igemm3s)
             wds = ops.pack_weight3s(cw, 9, cin, 1, cin * 9, 9, K=co)
             d_in, _ = ops.igemm3s(dy, wds, cin, B, Hh, Ww, flipped)
-        elif self.conv_mode == "bf16x3":
+        elif self._mfma3:
             wd3 = ops.pack_weight3(wsrc, len(taps), co, cin, s_tap, cin * 9, 9)
             d_in, _ = ops.igemm3(dy, wd3, cin, B, Hh, Ww, co, flipped)
         else:
@@ -607,8 +636,11 @@ class CRNN(_FlatModule):
         train = self.training
         drop = self.dropout_p if train else 0.0
         ctx = {"B": B, "blocks": [], "train": train, "seed": self.seed, "x": x} if save else None
+        self._check_bf16_mode()
         with ops.pack_cache(None if train else self._eval_plan):
             a, T = self._cnn_forward(x, ctx)
+            if a.dtype != torch.float32:
+                a = a.float()      # bf16 mode: the (B, T', 128) encoding enters the GRU as fp32 (28 MB at B = 256)
             seq, layers = self._gru_forward(a.view(B, T, self.nb_filters[-1]), B, T, "rnn", save)
         enc = ops.dropout(seq, drop, 200, self.seed) if drop > 0 else seq
         if save:
@@ -633,7 +665,7 @@ class CRNN(_FlatModule):
                 if on_early_grads is not None:
                     on_early_grads()
                 return
-            self._cnn_backward(ctx, d.view(B, T, 1, self.nb_filters[-1]), on_early_grads)
+            self._cnn_backward(ctx, d.view(B, T, 1, self.nb_filters[-1]).to(self.act_dtype), on_early_grads)
 
     def forward(self, x):
         if torch.is_grad_enabled() and self.training:
@@ -825,11 +857,12 @@ class CRNN_pred(CRNN):
         x = x.contiguous().float()
         B = x.shape[0]
         with ops.pack_cache(None if self.training else self._eval_plan):
+            self._check_bf16_mode()
             a, T = self._cnn_forward(x, None)
             C = self.nclass
-            feats = a.view(B, T, C)
+            feats = (a if a.dtype == torch.float32 else a.float()).view(B, T, C)   # bf16 mode: the head stays fp32
             w, b = self.P("dense_softmax.weight"), self.P("dense_softmax.bias")
-            if self.conv_mode == "bf16x3":
+            if self._mfma3:
                 w3 = ops.pack_weight3(w, 1, C, C, 0, 1, C)
                 logits, _ = ops.igemm3(feats, w3, C, 1, B * T, 1, C, ((0, 0),), bias=b)
             else:

@@ -21,7 +21,7 @@ class IgemmDesc(ctypes.Structure):
                 + [("dh", _i * 9), ("dw", _i * 9)]
                 + [(n, _i) for n in ("ph", "pw", "Hp", "Wp", "epilogue")]
                 + [("drop_p", ctypes.c_float), ("rng_stream", ctypes.c_uint32), ("seed", ctypes.c_uint64)]
-                + [("valid_h", _i), ("valid_w", _i)])
+                + [("valid_h", _i), ("valid_w", _i), ("act_bf16", _i)])
 
 
 class WgradDesc(ctypes.Structure):
@@ -29,7 +29,7 @@ class WgradDesc(ctypes.Structure):
                 + [(n, _i) for n in ("in_pitch", "dy_pitch", "NB", "H", "W", "CIN", "CINP", "N", "NP", "G", "TH", "TW",
                                      "tilesH", "tilesW", "hh", "hw", "ntaps")]
                 + [("dh", _i * 9), ("dw", _i * 9)]
-                + [(n, _fp) for n in ("bn_y", "bn_coef", "bn_mean", "dy_out")])
+                + [(n, _fp) for n in ("bn_y", "bn_coef", "bn_mean", "dy_out")] + [("act_bf16", _i)])
 
 
 class HeadBwdDesc(ctypes.Structure):
@@ -160,9 +160,27 @@ def _p(t):
     return L.ptr(t).value if t is not None else None
 
 
+def _pa(t):
+    """pointer of an ACTIVATION tensor: fp32, or bf16 in the "bf16" throughput mode (the C ABI keeps float* types)"""
+    return L.ptr(t, t.dtype if t is not None and t.dtype == torch.bfloat16 else None)
+
+
+def _abf(*ts):
+    """1 if the activation tensors are bf16 (all of them), 0 if fp32"""
+    ts = [t for t in ts if t is not None]
+    bf = [t.dtype == torch.bfloat16 for t in ts]
+    if any(bf) and not all(bf):
+        raise L.BsedError("mixed fp32 / bf16 activation tensors: " + ", ".join(str(t.dtype) for t in ts))
+    return 1 if bf and bf[0] else 0
+
+
+def _esz(t):
+    return 2.0 if t.dtype == torch.bfloat16 else 4.0
+
+
 def _dp(t, offset=0):
     """device pointer (int) of tensor storage + element offset; tensor need not be contiguous as a whole"""
-    return None if t is None else t.data_ptr() + 4 * offset
+    return None if t is None else t.data_ptr() + t.element_size() * offset
 
 
 def pack_weight(src, ntaps, K, N, s_tap, s_k, s_n, src_offset=0):
@@ -382,11 +400,12 @@ def igemm3s(inp, wtab, N, NB, H, W, taps, bias=None, epilogue=EPI_PLAIN):
     TH, TW = tile_for(W)
     NP = wtab.shape[0] * 32
     dev = inp.device
-    out = torch.empty((NB, H, W, N), device=dev, dtype=torch.float32)
+    out = torch.empty((NB, H, W, N), device=dev, dtype=inp.dtype)
     ntiles = NB * ((H + TH - 1) // TH) * (W // TW)
     G = int(min(ntiles, L.lib().bsed_igemm3s_auto_g2(_i(inp.shape[-1]), _i(N))))
     stats = torch.empty((G, 2, N), device=dev, dtype=torch.float32) if epilogue == EPI_STATS else None
-    d.in_ = _dp(inp); d.w = wtab.data_ptr(); d.bias = _p(bias); d.out = _p(out); d.stats = _p(stats)
+    d.act_bf16 = _abf(inp)
+    d.in_ = _dp(inp); d.w = wtab.data_ptr(); d.bias = _p(bias); d.out = out.data_ptr(); d.stats = _p(stats)
     CIN = 16 * wtab.shape[2]
     d.in_pitch, d.out_pitch, d.e_pitch = CIN, N, N
     d.NB, d.H, d.W, d.CIN, d.N, d.NP = NB, H, W, CIN, N, NP
@@ -398,8 +417,9 @@ def igemm3s(inp, wtab, N, NB, H, W, taps, bias=None, epilogue=EPI_PLAIN):
     d.ph = d.pw = 1; d.Hp, d.Wp = H, W
     d.epilogue = epilogue
     nv = 16 if N <= 16 and N % 4 == 0 else 32                      # transposed epilogue (bsed_igemm3s)
-    _launch((f"igemm3s_kernel<{1 if epilogue == EPI_STATS else 0}, {len(taps)}, {CIN // 16}, {nv}>", len(taps), CIN, N, H, W),
-            2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call("bsed_igemm3s", ctypes.byref(d), _i(G), L.stream()))
+    _launch((f"igemm3s_kernel<{1 if epilogue == EPI_STATS else 0}, {len(taps)}, {CIN // 16}, {nv}, {d.act_bf16}>", len(taps), CIN, N, H, W),
+            2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call("bsed_igemm3s", ctypes.byref(d), _i(G), L.stream()),
+            _esz(inp) * NB * H * W * (CIN + N))
     return out, stats
 
 
@@ -408,6 +428,8 @@ def igemm3(inp, w3, N, NB, H, W, CIN, taps, bias=None, epilogue=EPI_PLAIN, valid
     valid: see igemm."""
     if w3.dim() == 6:
         return _igemm3n(inp, w3, N, NB, H, W, CIN, taps, bias, epilogue, valid)
+    if inp.dtype != torch.float32:
+        raise L.BsedError("bf16 activations need the N-split kernel (BSED_IGEMM3N=1)")
     d = IgemmDesc()
     TH, TW = tile_for(W)
     NP = w3.shape[2]
@@ -462,9 +484,10 @@ def _igemm3n(inp, wtab, N, NB, H, W, CIN, taps, bias, epilogue, valid):
         raise L.BsedError(f"igemm3: weight table packed for K={wtab.shape[2] * 16}, {wtab.shape[1]} taps; "
                           f"called with CIN={CIN}, {len(taps)} taps")
     dev = inp.device
-    out = (torch.zeros if valid else torch.empty)((NB, H, W, N), device=dev, dtype=torch.float32)
+    out = (torch.zeros if valid else torch.empty)((NB, H, W, N), device=dev, dtype=inp.dtype)
     if valid:
         d.valid_h, d.valid_w = valid
+    d.act_bf16 = _abf(inp)
     d.in_pitch, d.out_pitch, d.e_pitch = CIN, N, N
     d.NB, d.H, d.W, d.CIN, d.N, d.NP = NB, H, W, CIN, N, NP
     d.TH, d.TW = TH, TW
@@ -476,14 +499,15 @@ def _igemm3n(inp, wtab, N, NB, H, W, CIN, taps, bias, epilogue, valid):
     d.epilogue = epilogue
     if IGEMM3N_WPE.get("stamp") is not None:   # diagnostic builds only (tools/conv_stamp.py, -DI3N_STAMP)
         d.e_src = IGEMM3N_WPE["stamp"].data_ptr()
-    d.in_ = _dp(inp); d.w = wtab.data_ptr(); d.bias = _p(bias); d.out = _p(out)
+    d.in_ = _dp(inp); d.w = wtab.data_ptr(); d.bias = _p(bias); d.out = out.data_ptr()
     rows = L.lib().bsed_igemm3n_stats_rows(ctypes.byref(d))
     var = L.lib().bsed_igemm3n_variant(ctypes.byref(d))
     stats = torch.empty((rows, 2, N), device=dev, dtype=torch.float32) if epilogue == EPI_STATS else None
     d.stats = _p(stats)
     _launch((f"igemm3n_kernel<{var & 15}, {(var >> 4) & 15}, {1 if epilogue == EPI_STATS else 0}, {(var >> 8) & 15}, "
-             f"{1 if len(taps) == 9 else 0}, {(var >> 12) & 15}>", len(taps), CIN, N, H, W),
-            2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call("bsed_igemm3n", ctypes.byref(d), L.stream()))
+             f"{1 if len(taps) == 9 else 0}, {(var >> 12) & 15}, {(var >> 16) & 1}>", len(taps), CIN, N, H, W),
+            2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call("bsed_igemm3n", ctypes.byref(d), L.stream()),
+            _esz(inp) * NB * H * W * (CIN + N))
     return out, stats
 
 
@@ -497,14 +521,17 @@ def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=Non
     dy_out then receives d_y for the data-gradient convolution."""
     import os
     mode = mode or WGRAD_MODE["mode"] or os.environ.get("BSED_CONV_MODE", "bf16x3")
-    sfx = "3" if mode == "bf16x3" else ""
+    sfx = "3" if mode in ("bf16x3", "bf16") else ""
     d = WgradDesc()
     TH, TW = tile_for(W)
     CINP, NP = round_up(CIN, 32), round_up(N, 32)
     ntiles = NB * ((H + TH - 1) // TH) * (W // TW)
     d.in_ = _dp(inp, in_offset); d.dy = _dp(dy, dy_offset)
     d.a_scale = _p(a_scale); d.a_shift = _p(a_shift)
-    d.bn_y, d.bn_coef, d.bn_mean, d.dy_out = _p(bn_y), _p(bn_coef), _p(bn_mean), _p(dy_out)
+    d.act_bf16 = _abf(inp, dy, bn_y, dy_out)
+    if d.act_bf16 and sfx != "3":
+        raise L.BsedError("bf16 activations need the split-fp32 / bf16 weight-gradient kernels (mode bf16x3 or bf16)")
+    d.bn_y, d.bn_coef, d.bn_mean, d.dy_out = _dp(bn_y), _p(bn_coef), _p(bn_mean), _dp(dy_out)
     d.in_pitch = CIN if in_pitch is None else in_pitch
     d.dy_pitch = N if dy_pitch is None else dy_pitch
     d.NB, d.H, d.W, d.CIN, d.CINP, d.N, d.NP, d.G = NB, H, W, CIN, CINP, N, NP, 0
@@ -522,16 +549,17 @@ def wgrad(inp, dy, NB, H, W, CIN, N, taps=((0, 0),), in_pitch=None, dy_pitch=Non
     # labels = the template instances as rocprofv3 prints them (bench.py joins the two by name)
     w1 = (var >> 13) & 1
     bs, geo, var = (var >> 12) & 1, (var >> 8) & 0xf, var & 0xff
+    ab = d.act_bf16
     if w1:
-        kname = f"wgrad1_kernel<{'true' if var & 1 else 'false'}>"
+        kname = f"wgrad1_kernel<{'true' if var & 1 else 'false'}, {ab}>"
     elif var % 16 == 1:
-        kname = f"wgrad3p_kernel<{var // 16}, {geo}>"
+        kname = f"wgrad3p_kernel<{var // 16}, {geo}, {ab}>"
     elif sfx:
-        kname = f"wgrad3_kernel<{var // 16}, {var % 16}, {'true' if bs else 'false'}>"
+        kname = f"wgrad3_kernel<{var // 16}, {var % 16}, {'true' if bs else 'false'}, {ab}>"
     else:
         kname = f"wgrad_kernel<{var // 16}, {var % 16}>"
     # algorithmic bytes: the input and dy once; with the fused BatchNorm backward also y (read) and d_y (written)
-    nbytes = 4.0 * NB * H * W * (CIN + N * (1 + (1 if bn_y is not None else 0) + (1 if dy_out is not None else 0)))
+    nbytes = _esz(inp) * NB * H * W * (CIN + N * (1 + (1 if bn_y is not None else 0) + (1 if dy_out is not None else 0)))
     _launch((kname, len(taps), CIN, N, H, W),
             2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call(f"bsed_wgrad{sfx}", ctypes.byref(d), L.stream()), nbytes)
     return part, G, CINP, NP
@@ -685,14 +713,16 @@ def block0_stats(x, cw, cb, NB, H, W):
     return stats, xr64
 
 
-def block0_fwd(x, cw, cb, scale, shift, wg, bg, B, H, W, pool, drop_p, rng_stream, seed):
+def block0_fwd(x, cw, cb, scale, shift, wg, bg, B, H, W, pool, drop_p, rng_stream, seed, out_dtype=torch.float32):
     ph, pw = pool
-    out = torch.empty((B, H // ph, W // pw, 16), device=x.device, dtype=torch.float32)
-    _note(f"b0_fwd_kernel<{ph}, {'true' if B * H * W < (1 << 28) else 'false'}>", f"{H}x{W}", 2.0 * B * H * W * (9 * 16 + 256),
-          4.0 * B * H * W * (1.0 + 16.0 / (ph * pw)))
+    out = torch.empty((B, H // ph, W // pw, 16), device=x.device, dtype=out_dtype)
+    ab = _abf(out)
+    small = "false" if ab else ("true" if B * H * W < (1 << 28) else "false")
+    _note(f"b0_fwd_kernel<{ph}, {small}, {ab}>", f"{H}x{W}", 2.0 * B * H * W * (9 * 16 + 256),
+          B * H * W * (4.0 + _esz(out) * 16.0 / (ph * pw)))
     L.call("bsed_block0_fwd", L.ptr(x), _fp(_dp(cw)), _fp(_dp(cb)), L.ptr(scale), L.ptr(shift), _fp(_dp(wg)),
-           _fp(_dp(bg)), L.ptr(out), _i(B), _i(H), _i(W), _i(16), _i(ph), _i(pw), ctypes.c_float(drop_p),
-           ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream())
+           _fp(_dp(bg)), _pa(out), _i(B), _i(H), _i(W), _i(16), _i(ph), _i(pw), ctypes.c_float(drop_p),
+           ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), _i(ab), L.stream())
     return out
 
 
@@ -706,12 +736,13 @@ def block0_bwd(x, cw, cb, scale, shift, wg, bg, dpool, B, H, W, pool, drop_p, rn
     part_db = torch.empty((G, 2, 16), device=dev, dtype=torch.float32)
     part_st = torch.empty((G, 2, 16), device=dev, dtype=torch.float32)
     part_gx = torch.empty((G, 9, 16), device=dev, dtype=torch.float32)
-    _note(f"b0_bwd_kernel<{ph}, {'true' if B * H * W < (1 << 28) else 'false'}>", f"{H}x{W}", 2.0 * B * H * W * (2 * 9 * 16 + 3 * 256),
-          4.0 * B * H * W * (1.0 + 16.0 / (ph * pw)))
+    ab = _abf(dpool)
+    _note(f"b0_bwd_kernel<{ph}, {'true' if B * H * W < (1 << 28) else 'false'}, {ab}>", f"{H}x{W}", 2.0 * B * H * W * (2 * 9 * 16 + 3 * 256),
+          B * H * W * (4.0 + _esz(dpool) * 16.0 / (ph * pw)))
     L.call("bsed_block0_bwd", L.ptr(x), _fp(_dp(cw)), _fp(_dp(cb)), L.ptr(scale), L.ptr(shift), _fp(_dp(wg)),
-           _fp(_dp(bg)), L.ptr(dpool), L.ptr(part_dw), L.ptr(part_db), L.ptr(part_st), L.ptr(part_gx), _i(G), _i(B),
+           _fp(_dp(bg)), _pa(dpool), L.ptr(part_dw), L.ptr(part_db), L.ptr(part_st), L.ptr(part_gx), _i(G), _i(B),
            _i(H), _i(W), _i(16), _i(ph), _i(pw), ctypes.c_float(drop_p), ctypes.c_uint32(rng_stream),
-           ctypes.c_uint64(seed), L.stream())
+           ctypes.c_uint64(seed), _i(ab), L.stream())
     return part_dw, part_db, part_st, part_gx, G
 
 
@@ -755,12 +786,13 @@ def glu_fwd3(y, scale, shift, w, bias, B, H, W, C, pool, drop_p, rng_stream, see
     TH, TW = tile_for(W)
     ntiles = B * ((H + TH - 1) // TH) * (W // TW)
     G = int(min(ntiles, L.lib().bsed_glu_fwd3_auto_g(C)))
-    out = torch.empty((B, H // ph, W // pw, C), device=y.device, dtype=torch.float32)
-    _launch((f"glu_fwd3_kernel<{C}, {4 if TW == 16 else -1}>", 1, C, C, H, W), 2.0 * B * H * W * C * C,
-            lambda: L.call("bsed_glu_fwd3", L.ptr(y), L.ptr(scale), L.ptr(shift), _fp(_dp(w)), _fp(_dp(bias)),
-                           L.ptr(out), _i(G), _i(B), _i(H), _i(W), _i(C), _i(TH), _i(TW), _i(ph), _i(pw),
-                           ctypes.c_float(drop_p), ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream()),
-            4.0 * B * H * W * C * (1.0 + 1.0 / (ph * pw)))  # y, pooled
+    out = torch.empty((B, H // ph, W // pw, C), device=y.device, dtype=y.dtype)
+    ab = _abf(y)
+    _launch((f"glu_fwd3_kernel<{C}, {4 if TW == 16 else -1}, {ab}>", 1, C, C, H, W), 2.0 * B * H * W * C * C,
+            lambda: L.call("bsed_glu_fwd3", _pa(y), L.ptr(scale), L.ptr(shift), _fp(_dp(w)), _fp(_dp(bias)),
+                           _pa(out), _i(G), _i(B), _i(H), _i(W), _i(C), _i(TH), _i(TW), _i(ph), _i(pw),
+                           ctypes.c_float(drop_p), ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), _i(ab), L.stream()),
+            _esz(y) * B * H * W * C * (1.0 + 1.0 / (ph * pw)))  # y, pooled
     return out
 
 
@@ -777,12 +809,13 @@ def glu_bwd3(y, scale, shift, w, bias, dpool, B, H, W, C, pool, drop_p, rng_stre
     part_db = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
     part_st = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
     flops = 3 * 2.0 * B * H * W * C * C
-    _launch((f"glu_bwd3_kernel<{C}, {4 if TW == 16 else -1}>", 1, C, C, H, W), flops,
-            lambda: L.call("bsed_glu_bwd3", L.ptr(y), L.ptr(scale), L.ptr(shift), _fp(_dp(w)), _fp(_dp(bias)),
-                           L.ptr(dpool), L.ptr(g), L.ptr(part_dw), L.ptr(part_db), L.ptr(part_st), _i(G), _i(B), _i(H),
+    ab = _abf(y, dpool)
+    _launch((f"glu_bwd3_kernel<{C}, {4 if TW == 16 else -1}, {ab}>", 1, C, C, H, W), flops,
+            lambda: L.call("bsed_glu_bwd3", _pa(y), L.ptr(scale), L.ptr(shift), _fp(_dp(w)), _fp(_dp(bias)),
+                           _pa(dpool), _pa(g), L.ptr(part_dw), L.ptr(part_db), L.ptr(part_st), _i(G), _i(B), _i(H),
                            _i(W), _i(C), _i(TH), _i(TW), _i(ph), _i(pw), ctypes.c_float(drop_p),
-                           ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), L.stream()),
-            4.0 * B * H * W * C * (2.0 + 1.0 / (ph * pw)))  # y, g, d_pooled
+                           ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed), _i(ab), L.stream()),
+            _esz(y) * B * H * W * C * (2.0 + 1.0 / (ph * pw)))  # y, g, d_pooled
     return g, part_dw, part_db, part_st, G, slabs
 
 
@@ -805,13 +838,14 @@ def glu_bwd3n(y, scale, shift, w, bias, dpool, B, H, W, C, pool, drop_p, rng_str
     dlin = torch.empty_like(y)
     part_db = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
     part_st = torch.empty((G, 2, C), device=dev, dtype=torch.float32)
-    _launch(("glu_bwd3n_kernel", 1, C, C, H, W), 2 * 2.0 * B * H * W * C * C,
-            lambda: L.call("bsed_glu_bwd3n", L.ptr(y), L.ptr(scale), L.ptr(shift), _fp(_dp(w)), _fp(_dp(bias)),
-                           L.ptr(dpool), L.ptr(g), L.ptr(dlin), L.ptr(part_db), L.ptr(part_st),
+    ab = _abf(y, dpool)
+    _launch((f"glu_bwd3n_kernel<{ab}>", 1, C, C, H, W), 2 * 2.0 * B * H * W * C * C,
+            lambda: L.call("bsed_glu_bwd3n", _pa(y), L.ptr(scale), L.ptr(shift), _fp(_dp(w)), _fp(_dp(bias)),
+                           _pa(dpool), _pa(g), _pa(dlin), L.ptr(part_db), L.ptr(part_st),
                            ctypes.c_void_p(tb.data_ptr()), _i(G), _i(B), _i(H), _i(W), _i(C), _i(TH), _i(TW), _i(ph),
                            _i(pw), ctypes.c_float(drop_p), ctypes.c_uint32(rng_stream), ctypes.c_uint64(seed),
-                           L.stream()),
-            4.0 * B * H * W * C * (3.0 + 1.0 / (ph * pw)))  # y, g, d_lin, d_pooled
+                           _i(ab), L.stream()),
+            _esz(y) * B * H * W * C * (3.0 + 1.0 / (ph * pw)))  # y, g, d_lin, d_pooled
     return g, dlin, part_db, part_st, G
 
 

@@ -111,6 +111,8 @@ typedef struct BsedIgemmDesc {
                                * enter the STATS sums ("valid" convolutions computed on a padded grid: the stride-2
                                * discriminator layers run as 2x2 stride-1 convolutions over space-to-depth input,
                                * whose last row / column of the grid is not an output).  PLAIN / STATS epilogues. */
+  int act_bf16;               /* bsed_igemm3n / bsed_igemm3s: 1 = `in` and `out` are bf16 tensors ("bf16" throughput mode:
+                               * one bf16 MFMA per product, fp32 accumulation, bias and statistics); 0 = fp32 */
 } BsedIgemmDesc;
 
 int bsed_igemm(const BsedIgemmDesc* desc /*host*/, void* stream);
@@ -173,6 +175,8 @@ typedef struct BsedWgradDesc {
   const float* bn_coef;
   const float* bn_mean;
   float* dy_out;
+  int act_bf16;          /* bsed_wgrad3: 1 = in, dy, bn_y and dy_out are bf16 tensors ("bf16" mode: one bf16 MFMA per product,
+                          * the BatchNorm-backward map and the accumulation in fp32); 0 = fp32 */
 } BsedWgradDesc;
 
 int bsed_wgrad(const BsedWgradDesc* desc /*host*/, void* stream);
@@ -285,11 +289,13 @@ int bsed_block0_stats(const float* x, const float* cw_t /* the (16,1,3,3) weight
                       int G, int NB, int H, int W, int CO, void* stream);
 int bsed_block0_fwd(const float* x, const float* cw, const float* cb, const float* scale, const float* shift,
                     const float* wg, const float* bg, float* out, int B, int H, int W, int CO, int ph, int pw,
-                    float drop_p, uint32_t rng_stream, uint64_t seed, void* stream);
+                    float drop_p, uint32_t rng_stream, uint64_t seed,
+                    int act_bf16 /* 1: the pooled output / its gradient is a bf16 tensor (bf16 mode) */, void* stream);
 int bsed_block0_bwd(const float* x, const float* cw, const float* cb, const float* scale, const float* shift,
                     const float* wg, const float* bg, const float* dpool, float* part_dw, float* part_db,
                     float* part_st, float* part_gx, int G, int B, int H, int W, int CO, int ph, int pw, float drop_p,
-                    uint32_t rng_stream, uint64_t seed, void* stream);
+                    uint32_t rng_stream, uint64_t seed,
+                    int act_bf16 /* 1: the pooled output / its gradient is a bf16 tensor (bf16 mode) */, void* stream);
 int bsed_block0_wgrad_finish(const float* part_gx, int G, const double* xr64, const float* coef, const float* mean,
                              const float* cw, const float* cb, float* dst, int accumulate, int CO, void* stream);
 
@@ -309,7 +315,7 @@ int bsed_glu_bwd_slabs(int C);
 int bsed_glu_bwd3(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
                   const float* dpool, float* g, float* part_dw, float* part_db, float* part_st, int G, int NB, int H,
                   int W, int C, int TH, int TW, int ph, int pw, float drop_p, uint32_t rng_stream, uint64_t seed,
-                  void* stream);
+                  int act_bf16 /* 1: y, d_pooled, g, d_lin, pooled are bf16 tensors (bf16 mode) */, void* stream);
 int bsed_glu_bwd3_slabs(int C);
 int bsed_glu_bwd3_auto_g(int C);
 /* C = 128 in the split-fp32 mode: g, db and BatchNorm partials as above, but d_lin (NB,H,W,128) is written out and
@@ -318,14 +324,16 @@ int bsed_glu_bwd3_auto_g(int C);
 int bsed_glu_bwd3n(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
                    const float* dpool, float* g, float* dlin, float* part_db, float* part_st, void* frag_table, int G,
                    int NB, int H, int W, int C, int TH, int TW, int ph, int pw, float drop_p, uint32_t rng_stream,
-                   uint64_t seed, void* stream);
+                   uint64_t seed,
+                  int act_bf16 /* 1: y, d_pooled, g, d_lin, pooled are bf16 tensors (bf16 mode) */, void* stream);
 size_t bsed_glu_bwd3n_table_bytes(void);
 /* Forward of the same stage in the split-fp32 mode, C in {32,64,128}: y (NB,H,W,C) -> pooled (NB,H/ph,W/pw,C);
  * replaces bsed_igemm(BSED_EPI_GLU_POOL) (GLU.forward + nn.Dropout + nn.AvgPool2d, src/models/CNN.py:5-16,59-67).
  * Vertical pooling (ph = 2) is supported for tile widths TW in {2,8,16}. */
 int bsed_glu_fwd3(const float* y, const float* scale, const float* shift, const float* w, const float* bias,
                   float* pooled, int G, int NB, int H, int W, int C, int TH, int TW, int ph, int pw, float drop_p,
-                  uint32_t rng_stream, uint64_t seed, void* stream);
+                  uint32_t rng_stream, uint64_t seed,
+                  int act_bf16 /* 1: y, d_pooled, g, d_lin, pooled are bf16 tensors (bf16 mode) */, void* stream);
 int bsed_glu_fwd3_auto_g(int C);
 
 /* ------------------------------------------------------------------------------------------------
