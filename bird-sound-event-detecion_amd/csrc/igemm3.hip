@@ -510,16 +510,29 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next tile's image is written
     } else {
+      // position m = (32 wave + 8 rg) [uniform] + 4 lh [lane] + q: three disjoint bit ranges, so the element offset is
+      // the sum of the parts' offsets -- one uniform 64-bit base per store, ONE per-lane byte offset (the epilogue's
+      // address arithmetic, a 64-bit multiply chain per element, was ~400 of a tile's instructions; csrc/igemm3n.hip)
+      constexpr uint32_t OSZ = ABF ? 2u : 4u;
+      auto eoff = [&](int m) { return ((m >> P.lgTW) * p.W + (m & (p.TW - 1))) * p.out_pitch; };
+      const int wu = __builtin_amdgcn_readfirstlane(wave);
+      char* ob = reinterpret_cast<char*>(p.out) + (((size_t)nb * p.H + th0) * p.W + tw0) * p.out_pitch * OSZ;
+      const uint32_t voff = (uint32_t)(eoff(4 * lh) + n) * OSZ;
+      const bool full = th0 + p.TH <= p.H;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int mm = wave * 32 + crow3(r, lh);
-        const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
-        if (gh < p.H && nok) {
-          const float v = acc[r] + bias;
-          act_st<ABF>(p.out, (((size_t)nb * p.H + gh) * p.W + gw) * p.out_pitch + n, v);
-          if (STATS) { s0 += v; s1 = fmaf(v, v, s1); }
+      for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int mu = wu * 32 + 8 * rg;
+          const bool ok = nok && (full || th0 + ((mu + 4 * lh + q) >> P.lgTW) < p.H);
+          if (ok) {
+            const float v = acc[4 * rg + q] + bias;
+            char* dst = ob + (size_t)(uint32_t)(eoff(mu) + eoff(q)) * OSZ + voff;
+            if (ABF) *reinterpret_cast<__bf16*>(dst) = (__bf16)v;
+            else *reinterpret_cast<float*>(dst) = v;
+            if (STATS) { s0 += v; s1 = fmaf(v, v, s1); }
+          }
         }
-      }
     }
   }
   if (STATS) {
