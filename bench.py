@@ -193,6 +193,9 @@ def main():
                     help="f32 (default, the parity headline): fp32 tensors, split-fp32 contractions; bf16: the throughput mode "
                          "BASELINE configs[1-2] name -- bf16 CNN activations in HBM, one bf16 MFMA per product, fp32 accumulation "
                          "/ statistics / master weights / optimizer (tolerances: tests/test_bf16_mode_gpu.py)")
+    ap.add_argument("--graph", action="store_true",
+                    help="--mode crnn: capture the step in a HIP graph (SEDTrainer.capture_step) and time replays; the "
+                         "per-launch kernel timer is off (events are not captured).  For the reference's batch: --batch 24")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="mel transform inside the step instead of one step ahead on the feature stream")
@@ -353,7 +356,17 @@ def main():
     if tr is not None:
         tr.arena.timing = world > 1 or tr.arena.exchange_single_rank
     log(f"data ready: B={B} n={n} T={T} Tp={Tp}")
-    use_timer = not args.no_kernel_timer and rank == 0
+    use_timer = not args.no_kernel_timer and rank == 0 and not args.graph
+    if args.graph:
+        if args.mode != "crnn" or world != 1:
+            raise SystemExit("--graph covers --mode crnn on one rank")
+        # the captured step transforms its own waveform batch (no cross-step feature pipeline inside a graph)
+        tr.capture_step(batches[0][0], batches[0][1], from_wave=True, warmup=max(args.warmup, 2))
+
+        def step():   # noqa: F811
+            w0, y0 = batches[count[0] % 2]
+            count[0] += 1
+            return tr.replay_step(w0, y0)
     # The warm-up runs with a throw-away kernel timer: the first few hundred HIP events of a process make the runtime
     # grow its signal pool (a one-time ~45 ms stall, measured on a fresh box), which must not land in the timed region.
     if use_timer:
@@ -531,7 +544,8 @@ def main():
                    "clip_seconds": args.seconds, "sr": args.sr, "frames": T, "out_frames": Tp,
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "dropout": 0.0 if args.mode == "cnn" else args.dropout,
-                   "input_pipeline": "none" if (args.mode == "cnn" or args.no_pipeline) else
+                   "hip_graph": bool(args.graph),
+                   "input_pipeline": "none" if (args.mode == "cnn" or args.no_pipeline or args.graph) else
                    "2 alternating resident batches; each step transforms the next step's waveforms (feature stream)"},
         "roofline": roofline, "cpu_baseline": cpu, "final_loss": round(loss, 5),
         "ranks_seen": ranks_seen, "data_parallel": dp,

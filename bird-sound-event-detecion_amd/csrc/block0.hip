@@ -287,7 +287,8 @@ __global__ __launch_bounds__(B0F_THREADS) void b0_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ cw, const float* __restrict__ cb,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ wg,
     const float* __restrict__ bg, float* __restrict__ out, int B, int H, int W, int pw, float drop_p,
-    uint32_t rng_stream, uint64_t seed) {
+    uint32_t rng_stream, uint64_t seed, const uint64_t* __restrict__ seed_add) {
+  if (seed_add) seed += *seed_add;
   constexpr int C = B0_C;
   __shared__ float wins[B0F_THREADS / 64][(PH + 2) * B0_WIN + 8];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, q = lane >> 4;
@@ -383,7 +384,8 @@ __global__ __launch_bounds__(B0B_THREADS, B0B_WPE) void b0_bwd_kernel(
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ wg,
     const float* __restrict__ bg, const float* __restrict__ dpool, float* __restrict__ part_dw,
     float* __restrict__ part_db, float* __restrict__ part_st, float* __restrict__ part_gx, int B, int H, int W, int pw,
-    float drop_p, uint32_t rng_stream, uint64_t seed) {
+    float drop_p, uint32_t rng_stream, uint64_t seed, const uint64_t* __restrict__ seed_add) {
+  if (seed_add) seed += *seed_add;
   constexpr int C = B0_C;
   __shared__ float red[B0B_THREADS * 17];
   __shared__ float wins[B0B_THREADS / 64][(PH + 2) * B0_WIN + 8];
@@ -621,7 +623,7 @@ extern "C" int bsed_block0_fwd(const float* x, const float* cw, const float* cb,
   const bool small = (long)B * H * W < (1L << 28);
 #define B0_LAUNCH_FWD(PH_, SM_, AB_)                                                                                 \
   hipLaunchKernelGGL((b0_fwd_kernel<PH_, SM_, AB_>), grid, dim3(B0F_THREADS), 0, s, x, cw, cb, scale, shift, wg, bg, out, B, \
-                     H, W, pw, drop_p, rng_stream, seed)
+                     H, W, pw, drop_p, rng_stream, seed, bsed_seed_add_ptr())
   if (act_bf16) { if (ph == 2) B0_LAUNCH_FWD(2, false, 1); else B0_LAUNCH_FWD(1, false, 1); }
   else if (ph == 2) { if (small) B0_LAUNCH_FWD(2, true, 0); else B0_LAUNCH_FWD(2, false, 0); }
   else { if (small) B0_LAUNCH_FWD(1, true, 0); else B0_LAUNCH_FWD(1, false, 0); }
@@ -644,7 +646,7 @@ extern "C" int bsed_block0_bwd(const float* x, const float* cw, const float* cb,
   const bool small = (long)B * H * W < (1L << 28);
 #define B0_LAUNCH_BWD(PH_, SM_, AB_)                                                                                  \
   hipLaunchKernelGGL((b0_bwd_kernel<PH_, SM_, AB_>), dim3(G), dim3(B0B_THREADS), 0, s, x, cw, cb, scale, shift, wg, bg, dpool, \
-                     part_dw, part_db, part_st, part_gx, B, H, W, pw, drop_p, rng_stream, seed)
+                     part_dw, part_db, part_st, part_gx, B, H, W, pw, drop_p, rng_stream, seed, bsed_seed_add_ptr())
   if (act_bf16) { if (ph == 2) { if (small) B0_LAUNCH_BWD(2, true, 1); else B0_LAUNCH_BWD(2, false, 1); }
                   else { if (small) B0_LAUNCH_BWD(1, true, 1); else B0_LAUNCH_BWD(1, false, 1); } }
   else if (ph == 2) { if (small) B0_LAUNCH_BWD(2, true, 0); else B0_LAUNCH_BWD(2, false, 0); }

@@ -10,6 +10,9 @@
 #define BSED_ERR_STATE (-3)
 
 void bsed_set_error(const char* fmt, ...);
+// device-resident step state (capi.hip): null in eager mode
+const uint64_t* bsed_seed_add_ptr();
+const int* bsed_step_add_ptr();
 
 #define BSED_CHECK_ARG(cond, ...)                 \
   do {                                            \

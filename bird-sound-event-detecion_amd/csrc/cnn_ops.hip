@@ -359,7 +359,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
 
 // elementwise dropout: out = in * keep/(1-p)   (forward and backward use the same call)
 __global__ void dropout_kernel(const float* __restrict__ in, float* __restrict__ out, long n, float p,
-                               uint32_t rng_stream, uint64_t seed) {
+                               uint32_t rng_stream, uint64_t seed, const uint64_t* __restrict__ seed_add) {
+  if (seed_add) seed += *seed_add;
   const uint32_t key = drop_key(rng_stream, seed), thr = drop_threshold(p);
   const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -513,7 +514,7 @@ extern "C" int bsed_dropout(const float* in, float* out, long n, float p, uint32
                             void* stream) {
   BSED_CHECK_ARG(in && out && n > 0 && p >= 0.f && p < 1.f, "bsed_dropout: bad argument");
   hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)std::min<long>(ceil_div(n, 256), 8192)), dim3(256), 0,
-                     (hipStream_t)stream, in, out, n, p, rng_stream, seed);
+                     (hipStream_t)stream, in, out, n, p, rng_stream, seed, bsed_seed_add_ptr());
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }

@@ -44,6 +44,7 @@ struct Glu3Params {
   int NB, H, W, TH, TW, lgTW, tilesH, tilesW, ntiles;
   int ph, pw, Hp, Wp;
   float drop_p; uint32_t rng_stream; uint64_t seed;
+  const uint64_t* seed_add;   // device-resident addend of the seed (HIP-graph replays), or null
 };
 
 static bool glu3_const_tw(const Glu3Params& P) {   // BSED_GLU3_LGTW=-1: runtime-geometry instances only (A/B runs)
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
 
   const int sph = P.ph >> 1, spw = P.pw >> 1;
   const float inv_pool = 1.0f / (float)(P.ph * P.pw);
-  const uint32_t dkey = drop_key(P.rng_stream, P.seed), dthr = drop_threshold(P.drop_p);
+  const uint32_t dkey = drop_key(P.rng_stream, P.seed + (P.seed_add ? *P.seed_add : 0)), dthr = drop_threshold(P.drop_p);
   const float dscale = P.drop_p > 0.f ? 1.0f / (1.0f - P.drop_p) : 1.0f;
 
   float bias[NT], csc[NT], csh[NT], sdb[NT], sgs[NT], sgy[NT];
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
 
   const int sph = P.ph >> 1, spw = P.pw >> 1;
   const float inv_pool = 1.0f / (float)(P.ph * P.pw);
-  const uint32_t dkey = drop_key(P.rng_stream, P.seed), dthr = drop_threshold(P.drop_p);
+  const uint32_t dkey = drop_key(P.rng_stream, P.seed + (P.seed_add ? *P.seed_add : 0)), dthr = drop_threshold(P.drop_p);
   const float dscale = P.drop_p > 0.f ? 1.0f / (1.0f - P.drop_p) : 1.0f;
 
   float bias[NT], csc[NT], csh[NT], sdb[NT], sgs[NT], sgy[NT];
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
 
   const int sph = P.ph >> 1, spw = P.pw >> 1;
   const float inv_pool = 1.0f / (float)(P.ph * P.pw);
-  const uint32_t dkey = drop_key(P.rng_stream, P.seed), dthr = drop_threshold(P.drop_p);
+  const uint32_t dkey = drop_key(P.rng_stream, P.seed + (P.seed_add ? *P.seed_add : 0)), dthr = drop_threshold(P.drop_p);
   const float dscale = P.drop_p > 0.f ? 1.0f / (1.0f - P.drop_p) : 1.0f;
   // register distance of the vertical pooling partner (position m + TW): crow(r + dr) = crow(r) + TW
   const int TW = TWc;
@@ -884,7 +885,7 @@ extern "C" int bsed_glu_bwd3(const float* y, const float* scale, const float* sh
   BSED_CHECK_ARG(G > 0 && G <= P.ntiles, "bsed_glu_bwd3: G must be in 1..%d tiles", P.ntiles);
   P.y = y; P.scale = scale; P.shift = shift; P.w = w; P.bias = bias; P.dpool = dpool;
   P.g = g; P.part_dw = part_dw; P.part_db = part_db; P.part_st = part_st; P.pooled = nullptr;
-  P.drop_p = drop_p; P.rng_stream = rng_stream; P.seed = seed;
+  P.drop_p = drop_p; P.rng_stream = rng_stream; P.seed = seed; P.seed_add = bsed_seed_add_ptr();
   hipStream_t s = (hipStream_t)stream;
   if (act_bf16) return C == 64 ? launch_glu_bwd3<64, 1>(P, G, s) : launch_glu_bwd3<32, 1>(P, G, s);
   if (C == 64) return launch_glu_bwd3<64, 0>(P, G, s);
@@ -911,7 +912,7 @@ extern "C" int bsed_glu_fwd3(const float* y, const float* scale, const float* sh
                  "bsed_glu_fwd3: vertical pooling is lane-local only for TW in {1,2,8,16} (got %d)", TW);
   P.y = y; P.scale = scale; P.shift = shift; P.w = w; P.bias = bias; P.dpool = nullptr;
   P.g = nullptr; P.part_dw = nullptr; P.part_db = nullptr; P.part_st = nullptr; P.pooled = pooled;
-  P.drop_p = drop_p; P.rng_stream = rng_stream; P.seed = seed;
+  P.drop_p = drop_p; P.rng_stream = rng_stream; P.seed = seed; P.seed_add = bsed_seed_add_ptr();
   hipStream_t s = (hipStream_t)stream;
   if (act_bf16) return C == 128 ? launch_glu_fwd3<128, 1>(P, G, s) : (C == 64 ? launch_glu_fwd3<64, 1>(P, G, s) : launch_glu_fwd3<32, 1>(P, G, s));
   if (C == 128) return launch_glu_fwd3<128, 0>(P, G, s);
@@ -937,7 +938,7 @@ extern "C" int bsed_glu_bwd3n(const float* y, const float* scale, const float* s
                  (P.ntiles + 1) / 2);
   P.y = y; P.scale = scale; P.shift = shift; P.w = w; P.bias = bias; P.dpool = dpool;
   P.g = g; P.part_dw = nullptr; P.part_db = part_db; P.part_st = part_st; P.pooled = nullptr;
-  P.drop_p = drop_p; P.rng_stream = rng_stream; P.seed = seed;
+  P.drop_p = drop_p; P.rng_stream = rng_stream; P.seed = seed; P.seed_add = bsed_seed_add_ptr();
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(glu3_pack_frags_kernel, dim3(4 * 8 * 64 / 256), dim3(256), 0, s, w, (bf16x8*)frag_table);
   const size_t smem = bsed_glu_bwd3n_table_bytes() + 2 * 128 * sizeof(float) + (size_t)8 * 32 * (2 * 16 + 8) * 2;

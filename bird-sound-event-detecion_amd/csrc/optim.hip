@@ -10,7 +10,11 @@
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
-                            float bc1, float bc2_sqrt, float gscale) {
+                            int step, const int* __restrict__ step_add, float gscale) {
+  // bias corrections from the step count ON THE DEVICE (step + *step_add): a captured launch replays with the count of
+  // the step it is replayed for; eager and replayed steps run the same arithmetic, hence the same bits
+  const float st = (float)(step + (step_add ? *step_add : 0));
+  const float bc1 = 1.f - powf(b1, st), bc2_sqrt = sqrtf(1.f - powf(b2, st));
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float gi = g[i] * gscale;
     const float pi = p[i];
@@ -77,10 +81,8 @@ static inline unsigned flat_grid(long n) { return (unsigned)std::min<long>(std::
 extern "C" int bsed_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                               float eps, float weight_decay, long step, float grad_scale, void* stream) {
   BSED_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "bsed_adam_step: bad argument");
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  const float bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
-                     beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+                     beta2, eps, weight_decay, (int)step, bsed_step_add_ptr(), grad_scale);
   BSED_LAUNCH_CHECK();
   return BSED_OK;
 }

@@ -17,6 +17,7 @@ but the first two CNN blocks' has been enqueued, and overlaps the rest of it; th
 the optimizer kernel.
 """
 import numpy as np
+import ctypes
 import os
 
 import torch
@@ -494,6 +495,60 @@ class SEDTrainer:
             update_ema_variables(pred, self.ema_predictor, self.ema_alpha, self.global_step)
         out["shape"] = (B, Tp, C)
         return out
+
+    # ------------------------------------------------------------------ HIP-graph replay of the plain step
+    def capture_step(self, syn_x, syn_y, from_wave=False, warmup=3):
+        """Capture the plain train step (synthetic batch only: BASELINE configs[2], the reference's ``train_mt`` without
+        ``-mt``) of THIS shape in a HIP graph.  At the reference's batch of 24 (src/data/config.py:70) a step is ~95
+        launches of 10-40 us each and the host needs 2.6 ms to enqueue what the GPU runs in < 2 ms: replaying a graph
+        removes the host from the loop.  What changes from step to step lives in DEVICE memory: the dropout seed addend
+        and the optimizer's step count (``bsed_set_step_state``), advanced by a node of the graph itself; inputs are
+        copied into the graph's static tensors.  ``warmup`` eager steps run first (allocator, weight-pack plan, lazy
+        tables).  Returns after the capture; then call ``replay_step(syn_x, syn_y)``.  Replayed steps are bit-identical
+        to eager ones (tests/test_graph_step_gpu.py)."""
+        if self.ema_crnn is not None or self.domain_loss is not None or self.world != 1:
+            raise L.BsedError("capture_step covers the plain single-rank step (no EMA teacher, no discriminator, no "
+                              "data-parallel group: their per-step host decisions are not graph nodes yet)")
+        dev = self.crnn.flat.device
+        self._g_x = syn_x.clone()
+        self._g_y = syn_y.clone()
+        self._g_from_wave = from_wave
+        for _ in range(warmup):
+            self._train_step(self._g_x, self._g_y, from_wave=from_wave)
+        # device-resident step state: zero addends now, the baked scalars are those of THIS step
+        self._g_state = torch.zeros(4, device=dev, dtype=torch.int64)     # [0] seed addend (uint64), [1] step addend (int32)
+        L.check(L.lib().bsed_set_step_state(ctypes.c_void_p(self._g_state[0:1].data_ptr()),
+                                            ctypes.c_void_p(self._g_state[1:2].data_ptr())), "bsed_set_step_state")
+        self._g_base_step = self.global_step
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        seed_inc = (parallel.rank_seed(self.seed, 1, self.rank) - parallel.rank_seed(self.seed, 0, self.rank)) * 4
+        with torch.cuda.graph(self._graph):
+            out = self._train_step(self._g_x, self._g_y, from_wave=from_wave)
+            L.check(L.lib().bsed_step_state_advance(ctypes.c_void_p(self._g_state[0:1].data_ptr()),
+                                                    ctypes.c_void_p(self._g_state[1:2].data_ptr()),
+                                                    ctypes.c_uint64(seed_inc), ctypes.c_int(1), L.stream()),
+                    "bsed_step_state_advance")
+        self._g_out = out
+        # the capture ran no kernel: undo its host-side bookkeeping (the first replay IS that step)
+        self.global_step = self._g_base_step
+        self.optimizer.step_count -= 1
+        return self
+
+    def replay_step(self, syn_x, syn_y):
+        """one captured step on new inputs (same shapes and dtypes as at capture); returns the same dict of device
+        tensors as ``train_step`` (overwritten by the next replay)"""
+        self._g_x.copy_(syn_x, non_blocking=True)
+        self._g_y.copy_(syn_y, non_blocking=True)
+        self._graph.replay()
+        self.global_step += 1
+        self.optimizer.step_count += 1
+        return self._g_out
+
+    def release_graph(self):
+        """back to eager steps: the library stops reading the device-resident step state"""
+        L.check(L.lib().bsed_set_step_state(None, None), "bsed_set_step_state")
+        self._graph = None
 
     # ------------------------------------------------------------------ ISP (shift-consistency) iteration
     def train_step_isp(self, syn_x, syn_y, real_x, real_y_weak, real_x_ema, shift_frames, shift_bins,

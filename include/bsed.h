@@ -505,6 +505,12 @@ int bsed_selftest_mfma(const float* A, const float* B, float* C, int K, void* st
 /* the same through v_mfma_f32_32x32x16_bf16 with bf16x3 split operands (K a multiple of 16) */
 int bsed_selftest_mfma_bf16x3(const float* A, const float* B, float* C, int K, void* stream);
 
+/* Device-resident step state for HIP-graph replays of a train step (csrc/capi.hip): when set, every kernel that takes a
+ * dropout seed adds *seed_add_dev (uint64) to it and the Adam kernel adds *step_add_dev (int) to its step count;
+ * bsed_step_state_advance is the graph node that bumps both after a step.  NULL, NULL = eager mode (the default). */
+int bsed_set_step_state(const void* seed_add_dev, const void* step_add_dev);
+int bsed_step_state_advance(void* seed_add_dev, void* step_add_dev, uint64_t seed_inc, int step_inc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
