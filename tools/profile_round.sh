@@ -28,3 +28,12 @@ python bench.py --steps 10 --no-cpu-baseline --sr 32000 > $OUT/${TAG}_bench_sr32
 BSED_CONV_MODE=fp32 python bench.py --steps 6 --no-cpu-baseline > $OUT/${TAG}_bench_fp32_mode.json 2> $OUT/${TAG}_bench_fp32_mode.log
 python bench.py --steps 20 --no-cpu-baseline --batch 24 > $OUT/${TAG}_bench_batch24.json 2> $OUT/${TAG}_bench_batch24.log
 echo "bench lines done"
+# round 3: the bf16 throughput mode (bench line + kernel stats), the HIP-graph replay at the reference's batch, the CNN tagger in bf16
+python bench.py --steps 20 --no-cpu-baseline --dtype bf16 > $OUT/${TAG}_bench_bf16.json 2> $OUT/${TAG}_bench_bf16.log
+python bench.py --steps 20 --no-cpu-baseline --dtype bf16 --mode cnn > $OUT/${TAG}_bench_cnn_bf16.json 2> $OUT/${TAG}_bench_cnn_bf16.log
+python bench.py --steps 10 --no-cpu-baseline --dtype bf16 --mode mt > $OUT/${TAG}_bench_mt_bf16.json 2> $OUT/${TAG}_bench_mt_bf16.log
+BSED_RNN_OVERLAP=0 python bench.py --steps 40 --no-cpu-baseline --batch 24 --graph > $OUT/${TAG}_bench_batch24_graph.json 2> $OUT/${TAG}_bench_batch24_graph.log
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats_bf16 -o out --output-format csv -- python3 $BENCH --dtype bf16 --steps 10 --warmup 2 > $OUT/${TAG}_stats_bf16.log 2>&1
+cd $R
+echo "round-3 extras done"
