@@ -242,7 +242,8 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
       for (int h = 0; h < 2; ++h) {
         const int rg = 2 * f + h;
         // branch-free: rows below the image / outside the pooled extent read a clamped address and are masked
-        float dv[4][NT], yv[4][NT], mk[4];
+        uint32_t dvr[4][NT], yvr[4][NT];
+        float mk[4];
         uint32_t posv[4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
@@ -254,10 +255,11 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
           const uint32_t dpo = ((uint32_t)(nb * P.Hp + min(gph, P.Hp - 1)) * (uint32_t)P.Wp + min(gpw, P.Wp - 1)) * C + li;
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
-            dv[rr][j] = act_ld<ABF>(P.dpool, dpo + 32 * j);
-            yv[rr][j] = act_ld<ABF>(P.y, posv[rr] + 32 * j);
+            dvr[rr][j] = act_ld_raw<ABF>(P.dpool, dpo + 32 * j);
+            yvr[rr][j] = act_ld_raw<ABF>(P.y, posv[rr] + 32 * j);
           }
         }
+        if (ABF) __builtin_amdgcn_sched_barrier(0);   // the group's loads are all issued before the first conversion
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int r = 4 * rg + rr;
@@ -265,10 +267,10 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             const int n = 32 * j + li;
-            const float xn = fmaf(yv[rr][j], csc[j], csh[j]);
+            const float xn = fmaf(act_cvt<ABF>(yvr[rr][j]), csc[j], csh[j]);
             const float sg = sigmoid_fast(xn);
             const float lin = acc[j][r] + bias[j];
-            const float dres = dv[rr][j] * mk[rr] * drop_mul32(posv[rr] + 32 * j, dkey, dthr, dscale);
+            const float dres = act_cvt<ABF>(dvr[rr][j]) * mk[rr] * drop_mul32(posv[rr] + 32 * j, dkey, dthr, dscale);
             const float dl = dres * sg;
             const float tt = dres * lin * sg * (1.0f - sg);
             sdb[j] += dl;
@@ -316,7 +318,8 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
     // ---- epilogue 2: write g, BatchNorm-backward sums (y re-read: cache-hot)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      float yv[4][NT], okf[4];
+      uint32_t yvr[4][NT];
+      float okf[4];
       uint32_t posv[4];
       float* gdst[4];
       uint32_t gidx[4];
@@ -329,8 +332,9 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
         gdst[rr] = gh < P.H ? P.g : g3_sink;  // rows below the image store to a sink: no branch
         gidx[rr] = gh < P.H ? posv[rr] : (uint32_t)li;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) yv[rr][j] = act_ld<ABF>(P.y, posv[rr] + 32 * j);
+        for (int j = 0; j < NT; ++j) yvr[rr][j] = act_ld_raw<ABF>(P.y, posv[rr] + 32 * j);
       }
+      if (ABF) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
           const float gv = acc[j][4 * rg + rr] * okf[rr];  // (rows below the image carry g = 0 anyway: d_lin = gate = 0)
           act_st<ABF>(gdst[rr], gidx[rr] + 32 * j, gv);
           sgs[j] += gv;
-          sgy[j] = fmaf(gv, yv[rr][j], sgy[j]);
+          sgy[j] = fmaf(gv, act_cvt<ABF>(yvr[rr][j]), sgy[j]);
         }
       }
     }
@@ -492,7 +496,8 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
     uint32_t dph[NT][8], dpl[NT][8];  // packed (r even | r odd << 16)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      float dv[4][NT], yv[4][NT], mk[4];
+      uint32_t dvr[4][NT], yvr[4][NT];
+      float mk[4];
       uint32_t posv[4];
       float* dlrow[4];
       uint32_t dlidx[4];
@@ -508,10 +513,11 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
         const uint32_t dpo = ((uint32_t)(nb * P.Hp + min(gph, P.Hp - 1)) * (uint32_t)P.Wp + min(gpw, P.Wp - 1)) * C + li;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          dv[rr][j] = act_ld<ABF>(P.dpool, dpo + 32 * j);
-          yv[rr][j] = act_ld<ABF>(P.y, posv[rr] + 32 * j);
+          dvr[rr][j] = act_ld_raw<ABF>(P.dpool, dpo + 32 * j);
+          yvr[rr][j] = act_ld_raw<ABF>(P.y, posv[rr] + 32 * j);
         }
       }
+      if (ABF) __builtin_amdgcn_sched_barrier(0);   // the group's loads are all issued before the first conversion
 #pragma unroll
       for (int rp = 0; rp < 2; ++rp)
 #pragma unroll
@@ -520,10 +526,10 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const int rr = 2 * rp + e, r = 4 * rg + rr;
-            const float xn = fmaf(yv[rr][j], csc[j], csh[j]);
+            const float xn = fmaf(act_cvt<ABF>(yvr[rr][j]), csc[j], csh[j]);
             const float sg = sigmoid_fast(xn);
             const float lin = acc[j][r] + bias[j];
-            const float dres = dv[rr][j] * mk[rr] * drop_mul32(posv[rr] + 32 * j, dkey, dthr, dscale);
+            const float dres = act_cvt<ABF>(dvr[rr][j]) * mk[rr] * drop_mul32(posv[rr] + 32 * j, dkey, dthr, dscale);
             const float dl = dres * sg;
             acc[j][r] = dres * lin * sg * (1.0f - sg);
             sdb[j] += dl;
@@ -565,7 +571,8 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
     // ---- epilogue 2: write g, BatchNorm-backward sums (y re-read: cache-hot)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      float yv[4][NT], okf[4];
+      uint32_t yvr[4][NT];
+      float okf[4];
       uint32_t posv[4];
       float* gdst[4];
       uint32_t gidx[4];
@@ -578,8 +585,9 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
         gdst[rr] = gh < P.H ? P.g : g3_sink;
         gidx[rr] = gh < P.H ? posv[rr] : (uint32_t)li;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) yv[rr][j] = act_ld<ABF>(P.y, posv[rr] + 32 * j);
+        for (int j = 0; j < NT; ++j) yvr[rr][j] = act_ld_raw<ABF>(P.y, posv[rr] + 32 * j);
       }
+      if (ABF) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
@@ -587,7 +595,7 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
           const float gv = acc[j][4 * rg + rr] * okf[rr];
           act_st<ABF>(gdst[rr], gidx[rr] + 32 * j, gv);
           sgs[j] += gv;
-          sgy[j] = fmaf(gv, yv[rr][j], sgy[j]);
+          sgy[j] = fmaf(gv, act_cvt<ABF>(yvr[rr][j]), sgy[j]);
         }
     }
   }
@@ -741,7 +749,8 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
     // ---- gate + dropout in place: acc <- (lin + b) * sigmoid(xn) * mask/(1-p)   (rows below the image -> 0)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      float yv[4][NT], mk[4];
+      uint32_t yvr[4][NT];
+      float mk[4];
       uint32_t posv[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
@@ -751,13 +760,14 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
         posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          yv[rr][j] = STAGE ? Ys[(8 * rg + lhv + rr) * YROW + 32 * j + li] : act_ld<ABF>(P.y, posv[rr] + 32 * j);
+          yvr[rr][j] = STAGE ? __float_as_uint(Ys[(8 * rg + lhv + rr) * YROW + 32 * j + li]) : act_ld_raw<ABF>(P.y, posv[rr] + 32 * j);
       }
+      if (ABF && !STAGE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const float xn = fmaf(yv[rr][j], csc[j], csh[j]);
+          const float xn = fmaf((STAGE ? __uint_as_float(yvr[rr][j]) : act_cvt<ABF>(yvr[rr][j])), csc[j], csh[j]);
           const float keep = mk[rr] * drop_mul32(posv[rr] + 32 * j, dkey, dthr, dscale);
           acc[j][4 * rg + rr] = (acc[j][4 * rg + rr] + bias[j]) * sigmoid_fast(xn) * keep;
         }

@@ -925,6 +925,144 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const float4 mu = *reinterpret_cast<const float4*>(p.bn_mean + cn);
       cC = make_float4(fmaf(-cB.x, mu.x, c2.x), fmaf(-cB.y, mu.y, c2.y), fmaf(-cB.z, mu.z, c2.z), fmaf(-cB.w, mu.w, c2.w));
     }
+    if constexpr (ABF) {
+      // ---- bf16 activations: 16-byte pieces of EIGHT channels (half the load / store / LDS-write instructions of the
+      // four-channel pieces), no hi / lo split: a piece goes to the hi plane as it arrives
+      constexpr int UX8 = (UX + 1) / 2, UD8 = UD / 2;
+      const int lgc8 = P.lgc4 - 1, c8n = 1 << lgc8, x_total8 = P.PP * c8n;
+      const int n8n = 4 * P.ntw, lgn8 = lgn4 - 1, d_total8 = IG_TILE_M * n8n;
+      float cA8[8], cB8[8], cC8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { cA8[q] = 1.f; cB8[q] = 0.f; cC8[q] = 0.f; }
+      if (bnb && n0 + 8 * (tid & (n8n - 1)) < p.N) {
+        const int cn = n0 + 8 * (tid & (n8n - 1));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          cA8[q] = p.bn_coef[cn + q];
+          cB8[q] = p.bn_coef[p.N + cn + q];
+          cC8[q] = fmaf(-cB8[q], p.bn_mean[cn + q], p.bn_coef[2 * p.N + cn + q]);
+        }
+      }
+      float sc8[8], sh8[8];
+      const bool affine = p.a_scale != nullptr;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { sc8[q] = 1.f; sh8[q] = 0.f; }
+      if (affine && cz0 + 8 * (tid & (c8n - 1)) < p.CIN) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          sc8[q] = p.a_scale[cz0 + 8 * (tid & (c8n - 1)) + q];
+          sh8[q] = p.a_shift[cz0 + 8 * (tid & (c8n - 1)) + q];
+        }
+      }
+      int xo[UX8], xg[UX8], xrc[UX8], dyo[UD8], dg[UD8], drc[UD8];
+#pragma unroll
+      for (int u = 0; u < UX8; ++u) {
+        const int e = tid + u * NTHR;
+        const int c8 = e & (c8n - 1), pos = e >> lgc8;
+        const int pr = (pos * P.pw_magic) >> 20, pc = pos - pr * PW;
+        xo[u] = pos * CC + (w3_chunk(c8 >> 2, pc, P.nct) << 5) + 8 * (c8 & 3);
+        xg[u] = ((pr - p.hh) * p.W + (pc - p.hw)) * p.in_pitch + cz0 + 8 * c8;
+        xrc[u] = (e < x_total8 && cz0 + 8 * c8 < p.CIN) ? ((pr - p.hh) << 16) | ((pc - p.hw) & 0xffff) : (0x4000 << 16);
+      }
+#pragma unroll
+      for (int u = 0; u < UD8; ++u) {
+        const int e = tid + u * NTHR;
+        const int n8 = e & (n8n - 1), mm = e >> lgn8;
+        const int r = mm >> P.lgTW, c = mm & (p.TW - 1);
+        dyo[u] = mm * DYW + (w3_chunk(n8 >> 2, mm, P.ntw) << 5) + 8 * (n8 & 3);
+        dg[u] = (r * p.W + c) * p.dy_pitch + n0 + 8 * n8;
+        drc[u] = (e < d_total8 && n0 + 8 * n8 < p.N) ? (r << 16) | c : (0x4000 << 16);
+      }
+      const unsigned short* in16 = reinterpret_cast<const unsigned short*>(p.in);
+      const unsigned short* dy16 = reinterpret_cast<const unsigned short*>(p.dy);
+      const unsigned short* y16 = reinterpret_cast<const unsigned short*>(p.bn_y);
+      unsigned short* out16 = reinterpret_cast<unsigned short*>(p.dy_out);
+      auto unpack8 = [](const bsed_u32x4& r, float* v) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(r[q] << 16); v[2 * q + 1] = __uint_as_float(r[q] & 0xFFFF0000u); }
+      };
+      auto pack8 = [](const float* v) {
+        bsed_u32x4 r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x2 t = {v[2 * q], v[2 * q + 1]};
+          r[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(t, bsed_bf16x2));
+        }
+        return r;
+      };
+      int buf = 0;
+      for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x, buf ^= 1) {
+        int t = tile;
+        const int tw_i = t % p.tilesW; t /= p.tilesW;
+        const int th_i = t % p.tilesH;
+        const int nb = t / p.tilesH;
+        const int th0 = th_i * p.TH, tw0 = tw_i * p.TW;
+        const size_t in_base = ((size_t)nb * p.H * p.W + (size_t)th0 * p.W + tw0) * p.in_pitch;
+        const size_t dy_base = ((size_t)nb * p.H * p.W + (size_t)th0 * p.W + tw0) * p.dy_pitch;
+        bsed_u32x4 vx[UX8], vd[UD8];
+        const bsed_u32x4 zero = {0u, 0u, 0u, 0u};
+        uint32_t okd = 0, okx = 0;
+#pragma unroll
+        for (int u = 0; u < UX8; ++u) {
+          const int gh_ = th0 + (xrc[u] >> 16), gw = tw0 + (int)(short)(xrc[u] & 0xffff);
+          vx[u] = zero;
+          if (gh_ >= 0 && gh_ < p.H && gw >= 0 && gw < p.W) {
+            vx[u] = *reinterpret_cast<const bsed_u32x4*>(in16 + (ptrdiff_t)in_base + xg[u]);
+            okx |= 1u << u;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UD8; ++u) {
+          const int gh_ = th0 + (drc[u] >> 16), gw = tw0 + (drc[u] & 0xffff);
+          vd[u] = zero;
+          if (gh_ < p.H && gw < p.W) {
+            vd[u] = *reinterpret_cast<const bsed_u32x4*>(dy16 + dy_base + dg[u]);
+            okd |= 1u << u;
+          }
+        }
+        if (bnb) {
+          bsed_u32x4 vy[UD8];
+#pragma unroll
+          for (int u = 0; u < UD8; ++u) {
+            vy[u] = zero;
+            if ((okd >> u) & 1) vy[u] = *reinterpret_cast<const bsed_u32x4*>(y16 + dy_base + dg[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < UD8; ++u) {
+            if ((okd >> u) & 1) {
+              float g8[8], y8[8];
+              unpack8(vd[u], g8); unpack8(vy[u], y8);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) g8[q] = fmaf(cA8[q], g8[q], fmaf(cB8[q], y8[q], cC8[q]));
+              vd[u] = pack8(g8);
+              if (dy_store) *reinterpret_cast<bsed_u32x4*>(out16 + dy_base + dg[u]) = vd[u];
+            }
+          }
+        }
+        const int bo = buf * buf_u16;
+#pragma unroll
+        for (int u = 0; u < UX8; ++u) {
+          if (tid + u * NTHR < x_total8) {
+            bsed_u32x4 v = vx[u];
+            if (affine && ((okx >> u) & 1)) {
+              float x8[8];
+              unpack8(v, x8);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) x8[q] = fmaf(x8[q], sc8[q], sh8[q]);
+              v = pack8(x8);
+            }
+            *reinterpret_cast<__attribute__((address_space(3))) bsed_u32x4*>(Xh + bo + xo[u]) = v;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UD8; ++u)
+          if (tid + u * NTHR < d_total8)
+            *reinterpret_cast<__attribute__((address_space(3))) bsed_u32x4*>(DYh + bo + dyo[u]) = vd[u];
+        __syncthreads();
+      }
+      __syncthreads();  // pairs with the consumers' barrier after their last tile
+      return;
+    }
     // tile-invariant element geometry: LDS offset, offset inside the image relative to the tile origin, patch row/col
     int xo[UX], xg[UX], xrc[UX], dyo[UD], dg[UD], drc[UD];
 #pragma unroll
