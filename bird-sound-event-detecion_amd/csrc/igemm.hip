@@ -18,6 +18,7 @@
 #include "bsed_common.h"
 #include "../../include/bsed.h"
 #include <algorithm>
+#include <type_traits>
 
 #define IG_THREADS 256
 #define IG_TILE_M 128
@@ -884,6 +885,24 @@ __host__ __device__ constexpr W3Geo w3_geo(int g) {
 }
 #define W3_NGEO 5
 
+// Diagnostic build (-DW3P_STAMP, tools/build_variant.sh + tools/wgrad_stamp.py): s_memtime stamps of the fourth tile period
+// of every workgroup -- slots 0..3 producer wave 4 (period start, loads landed, conversions + refills issued, barrier
+// passed), 4..6 consumer wave 0 (period start, MFMAs issued, barrier passed), 7 HW_ID.
+#ifdef W3P_STAMP
+__device__ unsigned long long w3p_stamp_buf[1024 * 8];
+extern "C" int bsed_w3p_stamps(unsigned long long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(w3p_stamp_buf), sizeof(w3p_stamp_buf)) == hipSuccess ? 0 : 1;
+}
+#define W3P_ST(slot, cond)                                                                                         \
+  if (cond) {                                                                                                      \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                    \
+    if ((threadIdx.x & 63) == 0)                                                                                   \
+      w3p_stamp_buf[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 1024 * 8 + (slot)] = t_;    \
+  }
+#else
+#define W3P_ST(slot, cond)
+#endif
+
 template <int MAXS, int GEO, int ABF>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad3p_kernel(const WgradParams P) {
   constexpr int NTHR = 256, NW = 4, UX = W3P_UX, UD = W3P_UD;
@@ -917,8 +936,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bool bnb = p.bn_y != nullptr;
     const bool dy_store = bnb && p.dy_out != nullptr && blockIdx.z == 0;   // one CIN chunk writes d_y out
     float4 cA = make_float4(1.f, 1.f, 1.f, 1.f), cB = make_float4(0.f, 0.f, 0.f, 0.f), cC = cB;
-    if (bnb && n0 + 4 * (tid & (n4n - 1)) < p.N) {
-      const int cn = n0 + 4 * (tid & (n4n - 1));
+    if (bnb) {
+      // (a thread whose channel quad lies beyond N works on quad 0 instead: its loads stay inside the tensor, its LDS
+      //  image is zeroed, and what it stores to dy_out is the value quad 0's owner stores there as well)
+      const int cn = n0 + 4 * (tid & (n4n - 1)) < p.N ? n0 + 4 * (tid & (n4n - 1)) : 0;
       cA = *reinterpret_cast<const float4*>(p.bn_coef + cn);
       cB = *reinterpret_cast<const float4*>(p.bn_coef + p.N + cn);
       const float4 c2 = *reinterpret_cast<const float4*>(p.bn_coef + 2 * p.N + cn);
@@ -931,38 +952,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       constexpr int UX8 = (UX + 1) / 2, UD8 = UD / 2;
       const int lgc8 = P.lgc4 - 1, c8n = 1 << lgc8, x_total8 = P.PP * c8n;
       const int n8n = 4 * P.ntw, lgn8 = lgn4 - 1, d_total8 = IG_TILE_M * n8n;
+      // (same software pipeline and straight-line period as the fp32 producers below -- see the comment there)
+      constexpr W3Geo Gm = w3_geo(GEO);
+      const int x_tot = GEO ? Gm.PP * (Gm.CC / 8) : x_total8, d_tot = GEO ? IG_TILE_M * 4 * Gm.ntw : d_total8;
+      const int gW = p.W, gH = p.H;
+      const bool xch_ok = cz0 + 8 * (tid & (c8n - 1)) < p.CIN, dch_ok = n0 + 8 * (tid & (n8n - 1)) < p.N;
+      const int xcoff = xch_ok ? cz0 + 8 * (tid & (c8n - 1)) : 0, dcoff = dch_ok ? n0 + 8 * (tid & (n8n - 1)) : 0;
       float cA8[8], cB8[8], cC8[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) { cA8[q] = 1.f; cB8[q] = 0.f; cC8[q] = 0.f; }
-      if (bnb && n0 + 8 * (tid & (n8n - 1)) < p.N) {
-        const int cn = n0 + 8 * (tid & (n8n - 1));
+      if (bnb) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          cA8[q] = p.bn_coef[cn + q];
-          cB8[q] = p.bn_coef[p.N + cn + q];
-          cC8[q] = fmaf(-cB8[q], p.bn_mean[cn + q], p.bn_coef[2 * p.N + cn + q]);
+          cA8[q] = p.bn_coef[dcoff + q];
+          cB8[q] = p.bn_coef[p.N + dcoff + q];
+          cC8[q] = fmaf(-cB8[q], p.bn_mean[dcoff + q], p.bn_coef[2 * p.N + dcoff + q]);
         }
       }
       float sc8[8], sh8[8];
       const bool affine = p.a_scale != nullptr;
 #pragma unroll
       for (int q = 0; q < 8; ++q) { sc8[q] = 1.f; sh8[q] = 0.f; }
-      if (affine && cz0 + 8 * (tid & (c8n - 1)) < p.CIN) {
+      if (affine && xch_ok) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          sc8[q] = p.a_scale[cz0 + 8 * (tid & (c8n - 1)) + q];
-          sh8[q] = p.a_shift[cz0 + 8 * (tid & (c8n - 1)) + q];
+          sc8[q] = p.a_scale[xcoff + q];
+          sh8[q] = p.a_shift[xcoff + q];
         }
       }
-      int xo[UX8], xg[UX8], xrc[UX8], dyo[UD8], dg[UD8], drc[UD8];
+      int xo[UX8], xrc[UX8], dyo[UD8], drc[UD8];
 #pragma unroll
       for (int u = 0; u < UX8; ++u) {
         const int e = tid + u * NTHR;
         const int c8 = e & (c8n - 1), pos = e >> lgc8;
-        const int pr = (pos * P.pw_magic) >> 20, pc = pos - pr * PW;
+        const int pr = GEO ? pos / (GEO ? Gm.PW : 1) : (pos * P.pw_magic) >> 20, pc = pos - pr * PW;
         xo[u] = pos * CC + (w3_chunk(c8 >> 2, pc, P.nct) << 5) + 8 * (c8 & 3);
-        xg[u] = ((pr - p.hh) * p.W + (pc - p.hw)) * p.in_pitch + cz0 + 8 * c8;
-        xrc[u] = (e < x_total8 && cz0 + 8 * c8 < p.CIN) ? ((pr - p.hh) << 16) | ((pc - p.hw) & 0xffff) : (0x4000 << 16);
+        xrc[u] = (e < x_tot && xch_ok) ? ((pr - p.hh) << 16) | ((pc - p.hw) & 0xffff) : (0x4000 << 16);
       }
 #pragma unroll
       for (int u = 0; u < UD8; ++u) {
@@ -970,8 +995,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int n8 = e & (n8n - 1), mm = e >> lgn8;
         const int r = mm >> P.lgTW, c = mm & (p.TW - 1);
         dyo[u] = mm * DYW + (w3_chunk(n8 >> 2, mm, P.ntw) << 5) + 8 * (n8 & 3);
-        dg[u] = (r * p.W + c) * p.dy_pitch + n0 + 8 * n8;
-        drc[u] = (e < d_total8 && n0 + 8 * n8 < p.N) ? (r << 16) | c : (0x4000 << 16);
+        drc[u] = (e < d_tot && dch_ok) ? (r << 16) | c : (0x4000 << 16);
       }
       const unsigned short* in16 = reinterpret_cast<const unsigned short*>(p.in);
       const unsigned short* dy16 = reinterpret_cast<const unsigned short*>(p.dy);
@@ -990,89 +1014,130 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         return r;
       };
-      int buf = 0;
-      for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x, buf ^= 1) {
+      struct TGeo { int th0, tw0; size_t in_img, dy_img; };
+      auto tgeo = [&](int tile) {
         int t = tile;
         const int tw_i = t % p.tilesW; t /= p.tilesW;
         const int th_i = t % p.tilesH;
         const int nb = t / p.tilesH;
-        const int th0 = th_i * p.TH, tw0 = tw_i * p.TW;
-        const size_t in_base = ((size_t)nb * p.H * p.W + (size_t)th0 * p.W + tw0) * p.in_pitch;
-        const size_t dy_base = ((size_t)nb * p.H * p.W + (size_t)th0 * p.W + tw0) * p.dy_pitch;
-        bsed_u32x4 vx[UX8], vd[UD8];
-        const bsed_u32x4 zero = {0u, 0u, 0u, 0u};
-        uint32_t okd = 0, okx = 0;
-#pragma unroll
-        for (int u = 0; u < UX8; ++u) {
-          const int gh_ = th0 + (xrc[u] >> 16), gw = tw0 + (int)(short)(xrc[u] & 0xffff);
-          vx[u] = zero;
-          if (gh_ >= 0 && gh_ < p.H && gw >= 0 && gw < p.W) {
-            vx[u] = *reinterpret_cast<const bsed_u32x4*>(in16 + (ptrdiff_t)in_base + xg[u]);
-            okx |= 1u << u;
-          }
-        }
+        TGeo g;
+        g.th0 = th_i * p.TH; g.tw0 = tw_i * p.TW;
+        g.in_img = (size_t)nb * p.H * p.W * p.in_pitch;
+        g.dy_img = (size_t)nb * p.H * p.W * p.dy_pitch;
+        return g;
+      };
+      auto x_at = [&](int u, const TGeo& g, bool& ok) {
+        const int gh_ = g.th0 + (xrc[u] >> 16), gw = g.tw0 + (int)(short)(xrc[u] & 0xffff);
+        ok = (unsigned)gh_ < (unsigned)gH && (unsigned)gw < (unsigned)gW;
+        return (uint32_t)((min(max(gh_, 0), gH - 1) * gW + min(max(gw, 0), gW - 1)) * p.in_pitch + xcoff) << 1;
+      };
+      auto d_at = [&](int u, const TGeo& g, bool& ok) {
+        const int gh_ = g.th0 + (drc[u] >> 16), gw = g.tw0 + (drc[u] & 0xffff);
+        ok = gh_ < gH && gw < gW;
+        return (uint32_t)((min(gh_, gH - 1) * gW + min(gw, gW - 1)) * p.dy_pitch + dcoff) << 1;
+      };
+      auto ld16 = [](const unsigned short* base, size_t img, uint32_t byte_off) {
+        return *reinterpret_cast<const bsed_u32x4*>(reinterpret_cast<const char*>(base + img) + byte_off);
+      };
+      const bsed_u32x4 zero = {0u, 0u, 0u, 0u};
+      auto produce = [&](auto bnb_c, auto store_c, auto aff_c) {
+        constexpr bool BNB = decltype(bnb_c)::value, STORE = decltype(store_c)::value, AFF = decltype(aff_c)::value;
+        bsed_u32x4 vx[UX8], vd[UD8], vy[BNB ? UD8 : 1];
+        int tile = blockIdx.x, buf = 0;
+        if (tile >= P.ntiles) return;
+        TGeo gc = tgeo(tile);
 #pragma unroll
         for (int u = 0; u < UD8; ++u) {
-          const int gh_ = th0 + (drc[u] >> 16), gw = tw0 + (drc[u] & 0xffff);
-          vd[u] = zero;
-          if (gh_ < p.H && gw < p.W) {
-            vd[u] = *reinterpret_cast<const bsed_u32x4*>(dy16 + dy_base + dg[u]);
-            okd |= 1u << u;
-          }
+          if (GEO && u * NTHR >= d_tot) continue;
+          bool ok;
+          const uint32_t o = d_at(u, gc, ok);
+          vd[u] = ld16(dy16, gc.dy_img, o);
+          if (BNB) vy[u] = ld16(y16, gc.dy_img, o);
         }
-        if (bnb) {
-          bsed_u32x4 vy[UD8];
-#pragma unroll
-          for (int u = 0; u < UD8; ++u) {
-            vy[u] = zero;
-            if ((okd >> u) & 1) vy[u] = *reinterpret_cast<const bsed_u32x4*>(y16 + dy_base + dg[u]);
-          }
-#pragma unroll
-          for (int u = 0; u < UD8; ++u) {
-            if ((okd >> u) & 1) {
-              float g8[8], y8[8];
-              unpack8(vd[u], g8); unpack8(vy[u], y8);
-#pragma unroll
-              for (int q = 0; q < 8; ++q) g8[q] = fmaf(cA8[q], g8[q], fmaf(cB8[q], y8[q], cC8[q]));
-              vd[u] = pack8(g8);
-              if (dy_store) *reinterpret_cast<bsed_u32x4*>(out16 + dy_base + dg[u]) = vd[u];
-            }
-          }
-        }
-        const int bo = buf * buf_u16;
 #pragma unroll
         for (int u = 0; u < UX8; ++u) {
-          if (tid + u * NTHR < x_total8) {
+          if (GEO && u * NTHR >= x_tot) continue;
+          bool ok;
+          vx[u] = ld16(in16, gc.in_img, x_at(u, gc, ok));
+        }
+        for (; tile < P.ntiles; buf ^= 1) {
+          const int nxt = tile + gridDim.x;
+          const TGeo gn = tgeo(nxt < P.ntiles ? nxt : tile);
+          const int bo = buf * buf_u16;
+#pragma unroll
+          for (int u = 0; u < UD8; ++u) {
+            if (GEO && u * NTHR >= d_tot) continue;
+            bool ok, okn;
+            const uint32_t o = d_at(u, gc, ok);
+            bsed_u32x4 v = vd[u];
+            if (BNB) {
+              float g8[8], y8[8];
+              unpack8(v, g8); unpack8(vy[u], y8);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) g8[q] = fmaf(cA8[q], g8[q], fmaf(cB8[q], y8[q], cC8[q]));
+              v = pack8(g8);
+              // unconditional (see the fp32 producers): a clamped piece stores the value its position's owner stores
+              if (STORE) *reinterpret_cast<bsed_u32x4*>(reinterpret_cast<char*>(out16 + gc.dy_img) + o) = v;
+            }
+            if (!ok) v = zero;
+            if (tid + u * NTHR < d_tot)
+              *reinterpret_cast<__attribute__((address_space(3))) bsed_u32x4*>(DYh + bo + dyo[u]) = v;
+            const uint32_t on = d_at(u, gn, okn);
+            vd[u] = ld16(dy16, gn.dy_img, on);
+            if (BNB) vy[u] = ld16(y16, gn.dy_img, on);
+          }
+#pragma unroll
+          for (int u = 0; u < UX8; ++u) {
+            if (GEO && u * NTHR >= x_tot) continue;
+            bool ok, okn;
+            (void)x_at(u, gc, ok);
             bsed_u32x4 v = vx[u];
-            if (affine && ((okx >> u) & 1)) {
+            if (AFF) {
               float x8[8];
               unpack8(v, x8);
 #pragma unroll
               for (int q = 0; q < 8; ++q) x8[q] = fmaf(x8[q], sc8[q], sh8[q]);
               v = pack8(x8);
             }
-            *reinterpret_cast<__attribute__((address_space(3))) bsed_u32x4*>(Xh + bo + xo[u]) = v;
+            if (!ok) v = zero;
+            if (tid + u * NTHR < x_tot)
+              *reinterpret_cast<__attribute__((address_space(3))) bsed_u32x4*>(Xh + bo + xo[u]) = v;
+            vx[u] = ld16(in16, gn.in_img, x_at(u, gn, okn));
           }
+          gc = gn; tile = nxt;
+          __syncthreads();
         }
-#pragma unroll
-        for (int u = 0; u < UD8; ++u)
-          if (tid + u * NTHR < d_total8)
-            *reinterpret_cast<__attribute__((address_space(3))) bsed_u32x4*>(DYh + bo + dyo[u]) = vd[u];
-        __syncthreads();
-      }
+      };
+      using T_ = std::true_type; using F_ = std::false_type;
+      if (!bnb) { if (affine) produce(F_{}, F_{}, T_{}); else produce(F_{}, F_{}, F_{}); }
+      else if (!dy_store) { if (affine) produce(T_{}, F_{}, T_{}); else produce(T_{}, F_{}, F_{}); }
+      else { if (affine) produce(T_{}, T_{}, T_{}); else produce(T_{}, T_{}, F_{}); }
       __syncthreads();  // pairs with the consumers' barrier after their last tile
       return;
     }
-    // tile-invariant element geometry: LDS offset, offset inside the image relative to the tile origin, patch row/col
-    int xo[UX], xg[UX], xrc[UX], dyo[UD], dg[UD], drc[UD];
+    // ---- fp32 activations.  Tile-invariant element geometry: LDS offset and patch row / col of each piece.  A thread's
+    // pieces all sit in one channel quad (256 threads are a multiple of the quads per position).
+    //
+    // SOFTWARE PIPELINE over tiles: the registers of a piece are refilled with the NEXT tile's piece right after the
+    // piece has been split into LDS, so a tile's loads have a whole tile period (one MFMA pass of the consumers) to
+    // arrive.  (Loading, waiting and converting inside one period took longer than the consumers' MFMA pass: the matrix
+    // cores idled behind the producers.)  Everything between two barriers is STRAIGHT-LINE code -- rows / columns outside
+    // the map are clamped for the address and zeroed at conversion, the last period re-requests its own tile -- because
+    // hipcc's wait-count insertion falls back to vmcnt(0) as soon as a load sits inside a branch, which would serialise
+    // the refills against the conversions.
+    constexpr W3Geo Gm = w3_geo(GEO);
+    const int x_tot = GEO ? Gm.PP * (Gm.CC / 4) : x_total, d_tot = GEO ? IG_TILE_M * 8 * Gm.ntw : d_total;
+    const int gW = p.W, gH = p.H;
+    int xo[UX], xrc[UX], dyo[UD], drc[UD];
+    const bool xch_ok = cz0 + 4 * (tid & (c4n - 1)) < p.CIN, dch_ok = n0 + 4 * (tid & (n4n - 1)) < p.N;
+    const int xcoff = xch_ok ? cz0 + 4 * (tid & (c4n - 1)) : 0, dcoff = dch_ok ? n0 + 4 * (tid & (n4n - 1)) : 0;
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
       const int e = tid + u * NTHR;
       const int c4 = e & (c4n - 1), pos = e >> P.lgc4;
-      const int pr = (pos * P.pw_magic) >> 20, pc = pos - pr * PW;
+      const int pr = GEO ? pos / (GEO ? Gm.PW : 1) : (pos * P.pw_magic) >> 20, pc = pos - pr * PW;
       xo[u] = pos * CC + (w3_chunk(c4 >> 3, pc, P.nct) << 5) + 4 * (c4 & 7);
-      xg[u] = ((pr - p.hh) * p.W + (pc - p.hw)) * p.in_pitch + cz0 + 4 * c4;
-      xrc[u] = (e < x_total && cz0 + 4 * c4 < p.CIN) ? ((pr - p.hh) << 16) | ((pc - p.hw) & 0xffff) : (0x4000 << 16);
+      xrc[u] = (e < x_tot && xch_ok) ? ((pr - p.hh) << 16) | ((pc - p.hw) & 0xffff) : (0x4000 << 16);
     }
 #pragma unroll
     for (int u = 0; u < UD; ++u) {
@@ -1080,77 +1145,111 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int n4 = e & (n4n - 1), mm = e >> lgn4;
       const int r = mm >> P.lgTW, c = mm & (p.TW - 1);
       dyo[u] = mm * DYW + (w3_chunk(n4 >> 3, mm, P.ntw) << 5) + 4 * (n4 & 7);
-      dg[u] = (r * p.W + c) * p.dy_pitch + n0 + 4 * n4;
-      drc[u] = (e < d_total && n0 + 4 * n4 < p.N) ? (r << 16) | c : (0x4000 << 16);
+      drc[u] = (e < d_tot && dch_ok) ? (r << 16) | c : (0x4000 << 16);
     }
-    int buf = 0;
-    for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x, buf ^= 1) {
+    struct TGeo { int th0, tw0; size_t in_img, dy_img; };
+    auto tgeo = [&](int tile) {
       int t = tile;
       const int tw_i = t % p.tilesW; t /= p.tilesW;
       const int th_i = t % p.tilesH;
       const int nb = t / p.tilesH;
-      const int th0 = th_i * p.TH, tw0 = tw_i * p.TW;
-      const float* inb = p.in + ((size_t)nb * p.H * p.W + (size_t)th0 * p.W + tw0) * p.in_pitch;
-      const size_t dy_base = ((size_t)nb * p.H * p.W + (size_t)th0 * p.W + tw0) * p.dy_pitch;
-      const float* dyb = p.dy + dy_base;
-      w3_f32x4 vx[UX], vd[UD];  // native vectors: arrays of HIP float4 structs end up in scratch
-      uint32_t okx = 0, okd = 0;
-#pragma unroll
-      for (int u = 0; u < UX; ++u) {
-        const int gh_ = th0 + (xrc[u] >> 16), gw = tw0 + (int)(short)(xrc[u] & 0xffff);
-        vx[u] = w3_f32x4{0.f, 0.f, 0.f, 0.f};
-        if (gh_ >= 0 && gh_ < p.H && gw >= 0 && gw < p.W) {
-          vx[u] = act_ld4<ABF>(p.in, (size_t)(inb + xg[u] - p.in));
-          okx |= 1u << u;
-        }
-      }
+      TGeo g;
+      g.th0 = th_i * p.TH; g.tw0 = tw_i * p.TW;
+      g.in_img = (size_t)nb * p.H * p.W * p.in_pitch;
+      g.dy_img = (size_t)nb * p.H * p.W * p.dy_pitch;
+      return g;
+    };
+    // byte offset of a piece inside its image (clamped into the map) and whether the piece is inside the map
+    auto x_at = [&](int u, const TGeo& g, bool& ok) {
+      const int gh_ = g.th0 + (xrc[u] >> 16), gw = g.tw0 + (int)(short)(xrc[u] & 0xffff);
+      ok = (unsigned)gh_ < (unsigned)gH && (unsigned)gw < (unsigned)gW;
+      return (uint32_t)((min(max(gh_, 0), gH - 1) * gW + min(max(gw, 0), gW - 1)) * p.in_pitch + xcoff) << 2;
+    };
+    auto d_at = [&](int u, const TGeo& g, bool& ok) {
+      const int gh_ = g.th0 + (drc[u] >> 16), gw = g.tw0 + (drc[u] & 0xffff);
+      ok = gh_ < gH && gw < gW;
+      return (uint32_t)((min(gh_, gH - 1) * gW + min(gw, gW - 1)) * p.dy_pitch + dcoff) << 2;
+    };
+    auto ld16 = [](const float* base, size_t img, uint32_t byte_off) {
+      return *reinterpret_cast<const w3_f32x4*>(reinterpret_cast<const char*>(base + img) + byte_off);
+    };
+    auto produce = [&](auto bnb_c, auto store_c) {
+      constexpr bool BNB = decltype(bnb_c)::value, STORE = decltype(store_c)::value;
+      w3_f32x4 vx[UX], vd[UD], vy[BNB ? UD : 1];  // native vectors: arrays of HIP float4 structs end up in scratch
+      int tile = blockIdx.x, buf = 0;
+      if (tile >= P.ntiles) return;
+      TGeo gc = tgeo(tile);
 #pragma unroll
       for (int u = 0; u < UD; ++u) {
-        const int gh_ = th0 + (drc[u] >> 16), gw = tw0 + (drc[u] & 0xffff);
-        vd[u] = w3_f32x4{0.f, 0.f, 0.f, 0.f};
-        if (gh_ < p.H && gw < p.W) {
-          vd[u] = act_ld4<ABF>(p.dy, (size_t)(dyb + dg[u] - p.dy));
-          okd |= 1u << u;
-        }
+        if (GEO && u * NTHR >= d_tot) continue;
+        bool ok;
+        const uint32_t o = d_at(u, gc, ok);
+        vd[u] = ld16(p.dy, gc.dy_img, o);
+        if (BNB) vy[u] = ld16(p.bn_y, gc.dy_img, o);
       }
-      if (bnb) {
-        // y rides in a second register set; d_y is formed here and (one CIN chunk only) written out for the dgrad
-        w3_f32x4 vy[UD];
-#pragma unroll
-        for (int u = 0; u < UD; ++u) {
-          vy[u] = w3_f32x4{0.f, 0.f, 0.f, 0.f};
-          if ((okd >> u) & 1) vy[u] = act_ld4<ABF>(p.bn_y, dy_base + dg[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < UD; ++u) {
-          if ((okd >> u) & 1) {
-            vd[u][0] = fmaf(cA.x, vd[u][0], fmaf(cB.x, vy[u][0], cC.x));
-            vd[u][1] = fmaf(cA.y, vd[u][1], fmaf(cB.y, vy[u][1], cC.y));
-            vd[u][2] = fmaf(cA.z, vd[u][2], fmaf(cB.z, vy[u][2], cC.z));
-            vd[u][3] = fmaf(cA.w, vd[u][3], fmaf(cB.w, vy[u][3], cC.w));
-            if (dy_store) act_st4<ABF>(p.dy_out, dy_base + dg[u], vd[u]);
-          }
-        }
-      }
-      // (the buffer being written was last read before the previous barrier)
-      const int bo = buf * buf_u16;
 #pragma unroll
       for (int u = 0; u < UX; ++u) {
-        if (tid + u * NTHR < x_total) {
-          float4 v = make_float4(vx[u][0], vx[u][1], vx[u][2], vx[u][3]);
-          if (p.a_scale && ((okx >> u) & 1)) {
-            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-            v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-          }
-          w3_store4<ABF>(Xh, Xl, bo + xo[u], v);
-        }
+        if (GEO && u * NTHR >= x_tot) continue;
+        bool ok;
+        vx[u] = ld16(p.in, gc.in_img, x_at(u, gc, ok));
       }
+      for (; tile < P.ntiles; buf ^= 1) {
+        const int nxt = tile + gridDim.x;
+        const TGeo gn = tgeo(nxt < P.ntiles ? nxt : tile);
+        // (the buffer being written was last read before the previous barrier)
+        const int bo = buf * buf_u16;
+#ifdef W3P_STAMP
+        const bool st_ = tile == (int)blockIdx.x + 3 * (int)gridDim.x && tid < 64;
+        W3P_ST(0, st_);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W3P_ST(1, st_);
+#endif
 #pragma unroll
-      for (int u = 0; u < UD; ++u)
-        if (tid + u * NTHR < d_total)
-          w3_store4<ABF>(DYh, DYl, bo + dyo[u], make_float4(vd[u][0], vd[u][1], vd[u][2], vd[u][3]));
-      __syncthreads();
-    }
+        for (int u = 0; u < UD; ++u) {
+          if (GEO && u * NTHR >= d_tot) continue;
+          bool ok, okn;
+          const uint32_t o = d_at(u, gc, ok);
+          w3_f32x4 v = vd[u];
+          if (BNB) {
+            // BatchNorm backward on load: d_y is formed here and (one CIN chunk only) written out for the dgrad
+            v[0] = fmaf(cA.x, v[0], fmaf(cB.x, vy[u][0], cC.x));
+            v[1] = fmaf(cA.y, v[1], fmaf(cB.y, vy[u][1], cC.y));
+            v[2] = fmaf(cA.z, v[2], fmaf(cB.z, vy[u][2], cC.z));
+            v[3] = fmaf(cA.w, v[3], fmaf(cB.w, vy[u][3], cC.w));
+            // unconditional: a piece outside the map was loaded from the clamped position, so it carries -- and stores
+            // -- exactly the value the owner of that position stores (no branch around a memory instruction)
+            if (STORE) *reinterpret_cast<w3_f32x4*>(reinterpret_cast<char*>(p.dy_out + gc.dy_img) + o) = v;
+          }
+          const float4 w = make_float4(ok ? v[0] : 0.f, ok ? v[1] : 0.f, ok ? v[2] : 0.f, ok ? v[3] : 0.f);
+          if (tid + u * NTHR < d_tot) w3_store4<ABF>(DYh, DYl, bo + dyo[u], w);
+          const uint32_t on = d_at(u, gn, okn);
+          vd[u] = ld16(p.dy, gn.dy_img, on);
+          if (BNB) vy[u] = ld16(p.bn_y, gn.dy_img, on);
+        }
+#pragma unroll
+        for (int u = 0; u < UX; ++u) {
+          if (GEO && u * NTHR >= x_tot) continue;
+          bool ok, okn;
+          (void)x_at(u, gc, ok);
+          const w3_f32x4 v = vx[u];
+          const float4 w = make_float4(ok ? fmaf(v[0], sc.x, sh.x) : 0.f, ok ? fmaf(v[1], sc.y, sh.y) : 0.f,
+                                       ok ? fmaf(v[2], sc.z, sh.z) : 0.f, ok ? fmaf(v[3], sc.w, sh.w) : 0.f);
+          if (tid + u * NTHR < x_tot) w3_store4<ABF>(Xh, Xl, bo + xo[u], w);
+          vx[u] = ld16(p.in, gn.in_img, x_at(u, gn, okn));
+        }
+#ifdef W3P_STAMP
+        W3P_ST(2, st_);
+#endif
+        gc = gn; tile = nxt;
+        __syncthreads();
+#ifdef W3P_STAMP
+        W3P_ST(3, st_);
+#endif
+      }
+    };
+    if (!bnb) produce(std::false_type{}, std::false_type{});
+    else if (!dy_store) produce(std::true_type{}, std::false_type{});
+    else produce(std::true_type{}, std::true_type{});
     __syncthreads();  // pairs with the consumers' barrier after their last tile
     return;
   }
@@ -1193,6 +1292,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // fragments of slot group g+1 are requested before the MFMAs of group g issue (two groups live at a time)
   constexpr int SG = 2, NG = (MAXS + SG - 1) / SG;
   for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x, buf ^= 1) {
+#ifdef W3P_STAMP
+    const bool st_ = tile == (int)blockIdx.x + 3 * (int)gridDim.x && tid < 64;
+    W3P_ST(4, st_);
+#endif
     if constexpr (GEO > 0) {
       constexpr W3Geo Gm = w3_geo(GEO);
       constexpr uint32_t kstep = 2 * (16 >> Gm.lgTW) * Gm.PW * Gm.CC, bstep = 2 * 16 * 32 * Gm.ntw;
@@ -1272,7 +1375,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       }
     }
+#ifdef W3P_STAMP
+    W3P_ST(5, st_);
+#endif
     __syncthreads();
+#ifdef W3P_STAMP
+    W3P_ST(6, st_);
+    if (st_ && lane == 0) {
+      unsigned hw_;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
+      w3p_stamp_buf[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 1024 * 8 + 7] = hw_;
+    }
+#endif
   }
   const int NPo = gridDim.y * DYW;
 #pragma unroll
