@@ -177,7 +177,7 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
   float* s_sc = reinterpret_cast<float*>(WB + NT * KS * 2 * 64);
   float* s_sh = s_sc + C;
   unsigned short* Dall = reinterpret_cast<unsigned short*>(s_sh + C);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
   unsigned short* D = Dall + wave * 32 * DP;  // wave-private
 
   build_weight_frags<C>(P.w, WF, WB, tid);
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
   float* s_sc = reinterpret_cast<float*>(WB + NT * KS * 2 * 64);
   float* s_sh = s_sc + C;
   unsigned short* Dall = reinterpret_cast<unsigned short*>(s_sh + C);
-  const int tid = threadIdx.x, wave8 = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wave = wave8 & 3, half = wave8 >> 2;  // wave = 32-row block of the tile, half = which of the two tiles
   unsigned short* D = Dall + wave8 * 32 * DQ;  // wave-private
 
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
   bf16x8* WF = reinterpret_cast<bf16x8*>(smem_raw);
   float* s_sc = reinterpret_cast<float*>(WF + NT * KS * 2 * 64);
   float* s_sh = s_sc + C;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, lh = lane >> 5;
   // C <= 64: the wave's 32 position rows of y are staged once, as whole lines (float4 per lane, 1 KB of consecutive
   // addresses per load instruction), into a wave-private LDS image that serves both reads of y -- the A fragments
   // (8 consecutive channels of the lane's position: 16-byte pieces of 32 different lines per instruction when read

@@ -337,3 +337,47 @@ def test_conv3x3_weight_gradient_bf16x3_matches_fp64_reference(B, H, W, cin, co,
         assert err < 4e-5, (nopipe, err)
     # both forms build the same products in the same order; they differ only in how many partial slabs are summed
     np.testing.assert_allclose(got[""].numpy(), got["1"].numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,cin,co", [
+    (2, 37, 16, 64, 128),    # every workgroup stores d_y (one input-channel chunk), ragged last tile row
+    (2, 61, 8, 128, 128),    # two input-channel chunks: only chunk 0 stores d_y
+    (3, 50, 32, 32, 64),     # 32-channel chunks, 5 slots
+    (2, 37, 16, 48, 48),     # channel quads beyond CIN / N: clamped loads, zeroed LDS image, duplicate d_y stores
+    (1, 70, 4, 128, 96),     # tall patch, N = 3 x 32
+])
+@pytest.mark.parametrize("act", ["f32", "bf16"])
+def test_conv3x3_weight_gradient_with_batchnorm_backward_on_load(B, H, W, cin, co, act):
+    """wgrad3p's producers form d_y = A g + B (y - mean) + C on load (BatchNorm backward, src/models/CNN.py:46-67's
+    nn.BatchNorm2d under autograd) and write it out once for the data-gradient convolution.  The producers are software
+    pipelined over tiles with clamped, branch-free loads: the cases cover ragged tile rows, one / two input-channel
+    chunks and channel counts that leave idle channel quads; fp32 and bf16 activations."""
+    from bsed_amd import ops
+    rng = np.random.default_rng(7 * H + W + cin)
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, W)).astype(np.float32))
+    g = torch.from_numpy(rng.standard_normal((B, co, H, W)).astype(np.float32))
+    y = torch.from_numpy(rng.standard_normal((B, co, H, W)).astype(np.float32))
+    coef = torch.from_numpy(rng.uniform(0.5, 1.5, (3, co)).astype(np.float32))
+    coef[1] *= 0.1
+    coef[2] *= 0.01
+    mean = torch.from_numpy(rng.standard_normal(co).astype(np.float32) * 0.2)
+    dt = torch.bfloat16 if act == "bf16" else torch.float32
+    xg, gg, yg = (_nhwc(t).to(dt).cuda() for t in (x, g, y))
+    xq, gq, yq = (t.float().cpu().permute(0, 3, 1, 2).double() for t in (xg, gg, yg))   # what the kernel really reads
+    A, Bc, Cc = (coef[i].double().view(1, -1, 1, 1) for i in range(3))
+    dy_ref = A * gq + Bc * (yq - mean.double().view(1, -1, 1, 1)) + Cc
+    dy_out = torch.full_like(gg, float("nan"))
+    part, G, KP, NP = ops.wgrad(xg, gg, B, H, W, cin, co, taps=ops.TAPS3x3, mode="bf16" if act == "bf16" else "bf16x3",
+                                bn_y=yg, bn_coef=coef.cuda(), bn_mean=mean.cuda(), dy_out=dy_out)
+    dw = torch.zeros((co, cin, 3, 3), device="cuda")
+    ops.reduce_partials(part, G, 9, KP, NP, cin, co, dw, 1, 9, cin * 9)
+    torch.cuda.synchronize()
+    tol_dy = 8e-3 if act == "bf16" else 2e-6      # bf16: d_y is rounded to bf16 (2^-9 relative) when stored
+    err_dy = float((dy_out.float().cpu().permute(0, 3, 1, 2).double() - dy_ref).abs().max() / dy_ref.abs().max())
+    assert err_dy < tol_dy, err_dy                 # every element written (no NaN left), none clobbered
+    # the contraction uses the d_y it formed: fp32 values (split-fp32 products) or their bf16 roundings (bf16 mode)
+    dy_used = dy_out.float().cpu().permute(0, 3, 1, 2).double() if act == "bf16" else dy_ref
+    ref = torch.nn.grad.conv2d_weight(xq, (co, cin, 3, 3), dy_used, padding=1)
+    err = float((dw.cpu().double() - ref).norm() / ref.norm())
+    assert err < (3e-3 if act == "bf16" else 4e-5), err
