@@ -1851,7 +1851,11 @@ static int launch_wgrad3p(const WgradParams& P, dim3 grid, size_t smem, hipStrea
 // its register arrays; everything else (1-tap forms, tall narrow patches) stays on wgrad3_kernel
 static bool wgrad3_pipelined(const WgradParams& P, size_t smem) {
   const int nitems = (P.pack2 ? (P.d.ntaps + 1) / 2 : P.d.ntaps) * P.nct * P.ntw;
-  static const int pipe_min = getenv("BSED_WGRAD3_PIPE_MIN") ? atoi(getenv("BSED_WGRAD3_PIPE_MIN")) : 8;  // A/B knob
+  // fewest (tap, chunk) items the pipelined kernel takes.  The 16 -> 32 channel layer (5 items: two taps per MFMA tile)
+  // is at the HBM rate in wgrad3_kernel with fp32 activations (0.69 ms vs 0.78 ms pipelined) but not with bf16 ones,
+  // where the pipelined producers' 16-byte pieces win (0.65 -> 0.41 ms).  BSED_WGRAD3_PIPE_MIN: A/B knob
+  static const int pipe_env = getenv("BSED_WGRAD3_PIPE_MIN") ? atoi(getenv("BSED_WGRAD3_PIPE_MIN")) : 0;
+  const int pipe_min = pipe_env > 0 ? pipe_env : (P.d.act_bf16 ? 4 : 8);
   static const bool onetap_pipe = getenv("BSED_WGRAD3_1TAP_PIPE") && getenv("BSED_WGRAD3_1TAP_PIPE")[0] == '1';
   if (P.d.ntaps == 1 && !onetap_pipe) return false;
   return nitems > (P.d.ntaps == 1 ? 3 : pipe_min) &&
