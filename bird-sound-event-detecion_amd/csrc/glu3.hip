@@ -122,19 +122,24 @@ __device__ __forceinline__ void build_weight_frags(const float* __restrict__ w, 
   }
 }
 
-// GEMM1 A fragments of this wave's 32 positions: BatchNorm-applied, split
+// GEMM1 A fragments of this wave's 32 positions: BatchNorm-applied, split.  Two halves so that a kernel can request the
+// NEXT tile's rows (a_frags_issue: raw values in registers) long before it needs them (a_frags_finish).
 template <int C, int ABF>
-__device__ __forceinline__ void load_a_frags(const Glu3Params& P, int lgTW, const float* s_sc, const float* s_sh, int nb,
-                                             int th0, int tw0, int wave, int li, int lh, bf16x8* a_hi, bf16x8* a_lo) {
+__device__ __forceinline__ float a_frags_issue(const Glu3Params& P, int lgTW, int nb, int th0, int tw0, int wave, int li, int lh,
+                                               float (&raw)[C / 16][8]) {
   constexpr int KS = C / 16;
   const int mA = wave * 32 + li;
   const int gh = th0 + (mA >> lgTW), gw = tw0 + (mA & ((1 << lgTW) - 1));
   const bool ok = gh < P.H;
   const size_t rp = (((size_t)nb * P.H + (ok ? gh : 0)) * P.W + gw) * C + 8 * lh;
-  float raw[KS][8];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) act_ld8<ABF>(P.y, rp + 16 * ks, raw[ks]);
-  const float okf = ok ? 1.0f : 0.0f;
+  return ok ? 1.0f : 0.0f;
+}
+template <int C>
+__device__ __forceinline__ void a_frags_finish(const float (&raw)[C / 16][8], float okf, const float* s_sc, const float* s_sh,
+                                               int lh, bf16x8* a_hi, bf16x8* a_lo) {
+  constexpr int KS = C / 16;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const float4 s0 = *reinterpret_cast<const float4*>(s_sc + 16 * ks + 8 * lh);
@@ -148,6 +153,13 @@ __device__ __forceinline__ void load_a_frags(const Glu3Params& P, int lgTW, cons
     v[6] = fmaf(raw[ks][6], s1.z, h1.z) * okf; v[7] = fmaf(raw[ks][7], s1.w, h1.w) * okf;
     split_pack8(v, a_hi[ks], a_lo[ks]);
   }
+}
+template <int C, int ABF>
+__device__ __forceinline__ void load_a_frags(const Glu3Params& P, int lgTW, const float* s_sc, const float* s_sh, int nb,
+                                             int th0, int tw0, int wave, int li, int lh, bf16x8* a_hi, bf16x8* a_lo) {
+  float raw[C / 16][8];
+  const float okf = a_frags_issue<C, ABF>(P, lgTW, nb, th0, tw0, wave, li, lh, raw);
+  a_frags_finish<C>(raw, okf, s_sc, s_sh, lh, a_hi, a_lo);
 }
 
 __device__ float g3_sink[G3_M];
@@ -202,12 +214,24 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
       for (int r = 0; r < 16; ++r) acc3[j][jc][r] = 0.f;
   }
 
+  // C = 32 (three waves per SIMD with registers to spare): the next tile's A rows are requested right after this tile's
+  // GEMM1 -- one of the tile's three dependent memory waits gone, and the lines are in L2 when epilogue 1 re-reads them
+  constexpr bool PREF = C == 32 && LGTW >= 0;   // (the runtime-width build would spill)
+  float nraw[KS][8];
+  float nokf = 0.f;
+  auto tile_origin = [&](int t, int& nb_, int& th0_, int& tw0_) {
+    const int tw_i = t % P.tilesW; t /= P.tilesW;
+    const int th_i = t % P.tilesH;
+    nb_ = t / P.tilesH; th0_ = th_i * THc; tw0_ = tw_i * TWc;
+  };
+  if (PREF && (int)blockIdx.x < P.ntiles) {
+    int nb_, th0_, tw0_;
+    tile_origin(blockIdx.x, nb_, th0_, tw0_);
+    nokf = a_frags_issue<C, ABF>(P, lgTW, nb_, th0_, tw0_, wave, li, lh, nraw);
+  }
   for (int tile0 = blockIdx.x; tile0 < P.ntiles; tile0 += gridDim.x) {
-    int tile = tile0;
-    const int tw_i = tile % P.tilesW; tile /= P.tilesW;
-    const int th_i = tile % P.tilesH;
-    const int nb = tile / P.tilesH;
-    const int th0 = th_i * THc, tw0 = tw_i * TWc;
+    int nb, th0, tw0;
+    tile_origin(tile0, nb, th0, tw0);
     // opaque copy of the lane's row offset: keeps the per-row index arithmetic of the epilogues (16 rows x several
     // values, all tile-invariant) from being hoisted out of the tile loop into ~40 long-lived registers
     int lhv = 4 * lh;
@@ -217,7 +241,8 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
     f32x16 acc[NT];
     {
       bf16x8 a_hi[KS], a_lo[KS];
-      load_a_frags<C, ABF>(P, lgTW, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
+      if (PREF) a_frags_finish<C>(nraw, nokf, s_sc, s_sh, lh, a_hi, a_lo);
+      else load_a_frags<C, ABF>(P, lgTW, s_sc, s_sh, nb, th0, tw0, wave, li, lh, a_hi, a_lo);
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -230,6 +255,12 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
           const bf16x8 b_lo = WF[((j * KS + ks) * 2 + 1) * 64 + lane];
           acc[j] = mfma_sp<ABF>(a_hi[ks], a_lo[ks], b_hi, b_lo, acc[j]);
         }
+    }
+    if (PREF) {   // (the last tile re-requests its own rows: no branch around the loads)
+      const int nt = tile0 + (int)gridDim.x < P.ntiles ? tile0 + (int)gridDim.x : tile0;
+      int nb_, th0_, tw0_;
+      tile_origin(nt, nb_, th0_, tw0_);
+      nokf = a_frags_issue<C, ABF>(P, lgTW, nb_, th0_, tw0_, wave, li, lh, nraw);
     }
 
     // ---- epilogue 1 (C layout: lane = channel 32j+li, register r = position wave*32 + crow(r, lh)).
