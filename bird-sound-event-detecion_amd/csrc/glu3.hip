@@ -217,6 +217,8 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
   // C = 32 (three waves per SIMD with registers to spare): the next tile's A rows are requested right after this tile's
   // GEMM1 -- one of the tile's three dependent memory waits gone, and the lines are in L2 when epilogue 1 re-reads them
   constexpr bool PREF = C == 32 && LGTW >= 0;   // (the runtime-width build would spill)
+  constexpr bool KEEPY = C == 32 && LGTW >= 0;
+  constexpr bool G2 = C == 32 && LGTW >= 0;     // epilogue 1 requests two row groups (16 loads) at a time
   float nraw[KS][8];
   float nokf = 0.f;
   auto tile_origin = [&](int t, int& nb_, int& th0_, int& tw0_) {
@@ -266,31 +268,40 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
     // ---- epilogue 1 (C layout: lane = channel 32j+li, register r = position wave*32 + crow(r, lh)).
     // d_lin and xn leave it already packed as the GEMM3 operand fragments (frag f = registers 8f..8f+7).
     bf16x8 da_hi[NT][2], da_lo[NT][2], xb_hi[NT][2], xb_lo[NT][2];
+    // C = 32: the 16 y values of the lane stay in registers for epilogue 2 (sum g y) instead of being read again
+    uint32_t ykeep[KEEPY ? 16 : 1][NT];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       float dl8[NT][8], xn8[NT][8];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      // branch-free: rows below the image / outside the pooled extent read a clamped address and are masked.
+      // The loads of a group (G2: of both row groups of the fragment) are ALL issued before the first conversion: left
+      // alone, hipcc puts each pair of loads directly in front of its use -- one L2 round trip per row, serialised
+      // (C = 32 backward 0.78 -> 0.68 ms with the fence alone).
+      uint32_t dvr[2][4][NT], yvr[2][4][NT];
+      float mk[2][4];
+      uint32_t posv[2][4];
+      auto issue = [&](int h) {
         const int rg = 2 * f + h;
-        // branch-free: rows below the image / outside the pooled extent read a clamped address and are masked
-        uint32_t dvr[4][NT], yvr[4][NT];
-        float mk[4];
-        uint32_t posv[4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int mm = wave * 32 + 8 * rg + lhv + rr;
           const int gh = th0 + (mm >> lgTW), gw = tw0 + (mm & (TWc - 1));
           const int gph = gh >> sph, gpw = gw >> spw;
-          mk[rr] = (gh < P.H && gph < P.Hp && gpw < P.Wp) ? inv_pool : 0.f;
-          posv[rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
+          mk[h][rr] = (gh < P.H && gph < P.Hp && gpw < P.Wp) ? inv_pool : 0.f;
+          posv[h][rr] = ((uint32_t)(nb * P.H + min(gh, P.H - 1)) * (uint32_t)P.W + gw) * C + li;
           const uint32_t dpo = ((uint32_t)(nb * P.Hp + min(gph, P.Hp - 1)) * (uint32_t)P.Wp + min(gpw, P.Wp - 1)) * C + li;
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
-            dvr[rr][j] = act_ld_raw<ABF>(P.dpool, dpo + 32 * j);
-            yvr[rr][j] = act_ld_raw<ABF>(P.y, posv[rr] + 32 * j);
+            dvr[h][rr][j] = act_ld_raw<ABF>(P.dpool, dpo + 32 * j);
+            yvr[h][rr][j] = act_ld_raw<ABF>(P.y, posv[h][rr] + 32 * j);
           }
         }
-        if (ABF) __builtin_amdgcn_sched_barrier(0);   // the group's loads are all issued before the first conversion
+      };
+      if (G2) { issue(0); issue(1); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int rg = 2 * f + h;
+        if (!G2) { issue(h); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int r = 4 * rg + rr;
@@ -298,10 +309,11 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             const int n = 32 * j + li;
-            const float xn = fmaf(act_cvt<ABF>(yvr[rr][j]), csc[j], csh[j]);
+            if (KEEPY) ykeep[r][j] = yvr[h][rr][j];
+            const float xn = fmaf(act_cvt<ABF>(yvr[h][rr][j]), csc[j], csh[j]);
             const float sg = sigmoid_fast(xn);
             const float lin = acc[j][r] + bias[j];
-            const float dres = act_cvt<ABF>(dvr[rr][j]) * mk[rr] * drop_mul32(posv[rr] + 32 * j, dkey, dthr, dscale);
+            const float dres = act_cvt<ABF>(dvr[h][rr][j]) * mk[h][rr] * drop_mul32(posv[h][rr] + 32 * j, dkey, dthr, dscale);
             const float dl = dres * sg;
             const float tt = dres * lin * sg * (1.0f - sg);
             sdb[j] += dl;
@@ -363,9 +375,9 @@ __global__ __launch_bounds__(G3_THREADS, C == 32 ? G3_B32_WPE : 2) void glu_bwd3
         gdst[rr] = gh < P.H ? P.g : g3_sink;  // rows below the image store to a sink: no branch
         gidx[rr] = gh < P.H ? posv[rr] : (uint32_t)li;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) yvr[rr][j] = act_ld_raw<ABF>(P.y, posv[rr] + 32 * j);
+        for (int j = 0; j < NT; ++j) yvr[rr][j] = KEEPY ? ykeep[4 * rg + rr][j] : act_ld_raw<ABF>(P.y, posv[rr] + 32 * j);
       }
-      if (ABF) __builtin_amdgcn_sched_barrier(0);
+      if (!KEEPY) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
@@ -548,7 +560,7 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
           yvr[rr][j] = act_ld_raw<ABF>(P.y, posv[rr] + 32 * j);
         }
       }
-      if (ABF) __builtin_amdgcn_sched_barrier(0);   // the group's loads are all issued before the first conversion
+      __builtin_amdgcn_sched_barrier(0);   // the group's loads are all issued before the first conversion
 #pragma unroll
       for (int rp = 0; rp < 2; ++rp)
 #pragma unroll
@@ -618,7 +630,7 @@ __global__ __launch_bounds__(G3N_THREADS) void glu_bwd3n_kernel(const Glu3Params
 #pragma unroll
         for (int j = 0; j < NT; ++j) yvr[rr][j] = act_ld_raw<ABF>(P.y, posv[rr] + 32 * j);
       }
-      if (ABF) __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
@@ -793,7 +805,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void glu_fwd3_kernel(const Glu3Param
         for (int j = 0; j < NT; ++j)
           yvr[rr][j] = STAGE ? __float_as_uint(Ys[(8 * rg + lhv + rr) * YROW + 32 * j + li]) : act_ld_raw<ABF>(P.y, posv[rr] + 32 * j);
       }
-      if (ABF && !STAGE) __builtin_amdgcn_sched_barrier(0);
+      if (!STAGE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
 #pragma unroll

@@ -7,6 +7,7 @@
 //                     and their gradients back to x, Wd, bd, Ws, bs in one pass
 //                     [reference src/main_baseline.py:431-498: nn.BCELoss (log clamped at -100, gradient
 //                      (s-y)/max(s(1-s),1e-12)), nn.MSELoss, all reduction='mean']
+#include <cstdlib>
 #include "bsed_common.h"
 #include "../../include/bsed.h"
 
@@ -35,22 +36,34 @@ __device__ __forceinline__ void head_stage_rows(float* dst, const float* __restr
   }
 }
 
-// logits for a chunk of frames: lg[f][0..C) dense head, lg[f][C..2C) softmax head
+// row of register r in the 32 x 32 MFMA result fragment (column = lane & 31, lh = lane >> 5)
+__device__ __forceinline__ int hd_crow(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+// logits for a chunk of frames: lg[f][0..C) dense head, lg[f][C..2C) softmax head.
+// The (32 frames x 2C) x 256 contraction runs on v_mfma_f32_32x32x2_f32 (f32 operands, exact fp32 products and sums): with
+// scalar FMAs every multiply-add paid an LDS read of the weight (1.2 reads per FMA: the kernel was LDS-bound).  Wave w
+// takes column tile w & 1 (classes 32 (w & 1) ..; columns beyond 2C compute on a clamped weight row and are dropped) and
+// the K half w >> 1; the two K halves meet in LDS.  Operands: one dword per lane and MFMA, conflict-free (pitch 257).
 template <int C>
 __device__ __forceinline__ void head_logits(const float* xs /*[HD_FR][HD_K+1]*/, const float* ws /*[2C][HD_K+1]*/,
-                                            const float* bs /*[2C]*/, float* lg /*[HD_FR][2C]*/, int tid) {
-  constexpr int PER = (2 * C) / 8;  // outputs per thread (8 threads per frame)
-  const int f = tid >> 3, cg = tid & 7;
-  float acc[PER];
+                                            const float* bs /*[2C]*/, float* lg /*[HD_FR][2C]*/,
+                                            float* lgp /*[2][HD_FR][2C] scratch*/, int tid) {
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int nt = wave & 1, kh = wave >> 1;
+  const int n = 32 * nt + li;
+  const float* ap = xs + li * (HD_K + 1) + (HD_K / 2) * kh + lh;
+  const float* bp = ws + min(n, 2 * C - 1) * (HD_K + 1) + (HD_K / 2) * kh + lh;
+  f32x16 acc;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) acc[i] = bs[cg * PER + i];
-  for (int k = 0; k < HD_K; ++k) {
-    const float xv = xs[f * (HD_K + 1) + k];
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+  for (int s = 0; s < HD_K / 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
+  if (n < 2 * C) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) acc[i] = fmaf(xv, ws[(cg * PER + i) * (HD_K + 1) + k], acc[i]);
+    for (int r = 0; r < 16; ++r) lgp[(kh * HD_FR + hd_crow(r, lh)) * (2 * C) + n] = acc[r];
   }
-#pragma unroll
-  for (int i = 0; i < PER; ++i) lg[f * (2 * C) + cg * PER + i] = acc[i];
+  __syncthreads();
+  for (int e = tid; e < HD_FR * 2 * C; e += HD_THREADS) lg[e] = (lgp[e] + lgp[HD_FR * 2 * C + e]) + bs[e % (2 * C)];
 }
 
 template <int C>
@@ -66,6 +79,8 @@ __global__ __launch_bounds__(HD_THREADS) void head_fwd_kernel(
   float* bsm = lg + HD_FR * 2 * C;           // [2C]
   float* sS = bsm + 2 * C;                   // [32][C]
   float* sA = sS + HD_FR * C;                // [32][C]
+  float* lgp = sS;                           // [2][32][2C] K-half partials of head_logits: over sS | sA and 32*2C more
+  float* exS = sA + HD_FR * C;               // [32][C] exp(logit - max): the second half of lgp (dead after head_logits)
   const int tid = threadIdx.x, b_ = blockIdx.x;
   head_stage_rows<2 * C>(ws, w, 2 * C, tid);
   if (tid < 2 * C) bsm[tid] = b[tid];
@@ -79,25 +94,42 @@ __global__ __launch_bounds__(HD_THREADS) void head_fwd_kernel(
     __syncthreads();
     head_stage_rows<HD_FR>(xs, x + ((size_t)b_ * T + f0) * HD_K, T - f0, tid);
     __syncthreads();
-    head_logits<C>(xs, ws, bsm, lg, tid);
+    head_logits<C>(xs, ws, bsm, lg, lgp, tid);   // (sS / sA of the previous chunk were consumed before the barrier above)
     __syncthreads();
-    if (tid < HD_FR) {
-      const int f = tid;
-      const bool ok = f0 + f < T;
-      float mx = -3.0e38f;
-      for (int c = 0; c < C; ++c) mx = fmaxf(mx, lg[f * 2 * C + C + c]);
-      float e[C], se = 0.f;
-      for (int c = 0; c < C; ++c) { e[c] = expf(lg[f * 2 * C + C + c] - mx); se += e[c]; }
-      const float inv = 1.0f / se;
-      for (int c = 0; c < C; ++c) {
-        const float s = sigmoidf_(lg[f * 2 * C + c]);
-        const float p = e[c] * inv;
+    // sigmoid / softmax over the classes, one (frame, class) element per thread and round (one THREAD per frame walking
+    // its 20 classes -- 40 full-precision exponentials and 40 stores in a dependent chain on 32 of the 256 lanes -- was
+    // most of the kernel's time).  Same operations in the same order per element: max, exp, sum over c = 0..C-1, 1/sum.
+    float sv[(HD_FR * C + HD_THREADS - 1) / HD_THREADS];
+#pragma unroll
+    for (int u = 0; u < (HD_FR * C + HD_THREADS - 1) / HD_THREADS; ++u) {
+      const int e = tid + u * HD_THREADS;
+      if (e < HD_FR * C) {
+        const int f = e / C, c = e - f * C;
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) mx = fmaxf(mx, lg[f * 2 * C + C + cc]);
+        exS[e] = expf(lg[f * 2 * C + C + c] - mx);
+        sv[u] = sigmoidf_(lg[f * 2 * C + c]);
+      }
+    }
+    __syncthreads();   // (also: every read of lgp's first half -- aliased by sS below -- is long done)
+#pragma unroll
+    for (int u = 0; u < (HD_FR * C + HD_THREADS - 1) / HD_THREADS; ++u) {
+      const int e = tid + u * HD_THREADS;
+      if (e < HD_FR * C) {
+        const int f = e / C;
+        const bool ok = f0 + f < T;
+        float se = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < C; ++cc) se += exS[f * C + cc];
+        const float inv = 1.0f / se;
+        const float p = exS[e] * inv;
         const float a = attention ? fminf(fmaxf(p, 1e-7f), 1.0f) : 1.0f;
-        sS[f * C + c] = ok ? s : 0.f;
-        sA[f * C + c] = ok ? a : 0.f;
+        sS[e] = ok ? sv[u] : 0.f;
+        sA[e] = ok ? a : 0.f;
         if (ok) {
-          strong[((size_t)b_ * T + f0 + f) * C + c] = s;
-          sof_raw[((size_t)b_ * T + f0 + f) * C + c] = p;
+          strong[((size_t)b_ * T + f0) * C + e] = sv[u];
+          sof_raw[((size_t)b_ * T + f0) * C + e] = p;
         }
       }
     }
@@ -189,6 +221,8 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_kernel(
   float* wk = gwk + C;                       // [C]
   float* dn = wk + C;                        // [C]
   float* lred = dn + C;                      // [HD_THREADS]
+  float* gaS = lred + HD_THREADS;            // [32][C] attention-path gradient of the softmax output
+  float* paS = gaS + HD_FR * C;              // [32][C] softmax output
   const int tid = threadIdx.x, b_ = blockIdx.x;
   // time splits as in head_fwd_kernel; partial outputs (dW, db, losses) get one row per (clip, split)
   const int S = gridDim.y, sp = blockIdx.y;
@@ -215,90 +249,129 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_kernel(
     wk[tid] = wv;
     dn[tid] = den[(size_t)b_ * C + tid];
   }
-  float dwacc[2 * C];
+  // The three contractions of the chunk loop run on v_mfma_f32_32x32x2_f32 (f32 operands: exact fp32, like the scalar
+  // FMAs they replace, which paid one or two LDS reads per multiply-add).  Wave w owns columns 64 w .. 64 w + 63 of K:
+  //   dx[f][k]  = sum_c dl[f][c] W[c][k]        32 frames x 64 columns, 2C / 2 steps
+  //   dW[c][k] += sum_f dl[f][c] x[f][k]        2 x 32 class rows (rows >= 2C idle) x 64 columns, 16 steps;
+  //                                             the four 32 x 32 accumulators live across the chunks
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  f32x16 dwa[2][2];
 #pragma unroll
-  for (int c = 0; c < 2 * C; ++c) dwacc[c] = 0.f;
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dwa[mt][j][r] = 0.f;
   float dbacc = 0.f;  // thread c < 2C accumulates its bias gradient
+  const bool has_ys = y_strong != nullptr, has_es = ema_strong != nullptr, has_es2 = ema_strong2 != nullptr,
+             has_gx = g_strong_ext != nullptr;
   for (int f0 = f_lo; f0 < f_hi; f0 += HD_FR) {
     __syncthreads();
     head_stage_rows<HD_FR>(xs, x + ((size_t)b_ * T + f0) * HD_K, T - f0, tid);
-    if (tid < HD_FR) {
-      const int f = tid;
+    // loss gradients, one (frame, class) element per thread and round -- consecutive threads read consecutive addresses,
+    // frames past T read the last frame and are masked (no branch around the loads; with one THREAD per frame walking
+    // its 20 classes every load waited for the one before it)
+    for (int e = tid; e < HD_FR * C; e += HD_THREADS) {
+      const int f = e / C, c = e - f * C;
       const bool ok = f0 + f < T;
-      const size_t o = ((size_t)b_ * T + f0 + f) * C;
-      float ga[C], pa[C], dot = 0.f;
-      for (int c = 0; c < C; ++c) {
-        float dls = 0.f;
-        ga[c] = 0.f; pa[c] = 0.f;
-        if (ok) {
-          const float s = strong[o + c];
-          const float p = sof_raw[o + c];
-          const float a = attention ? fminf(fmaxf(p, 1e-7f), 1.0f) : 1.0f;
-          float gs = gwk[c] * a / dn[c];
-          if (y_strong) {
-            const float yv = y_strong[o + c];
-            gs += w_strong * bce_grad(s, yv) * inv_n_strong;
-            l_s += bce_val(s, yv);
-          }
-          if (ema_strong) {
-            const float d = s - ema_strong[o + c];
-            gs += w_cons_s * 2.f * d * inv_n_strong;
-            l_cs += d * d;
-          }
-          if (ema_strong2) {
-            const float d = s - ema_strong2[o + c];
-            gs += w_cons_s2 * 2.f * d * inv_n_strong;
-            l_cs2 += d * d;
-          }
-          if (g_strong_ext) gs += g_strong_ext[o + c];
-          dls = gs * s * (1.f - s);
-          if (attention && p >= 1e-7f && p <= 1.0f) ga[c] = gwk[c] * (s - wk[c]) / dn[c];
-          pa[c] = p;
-          dot = fmaf(ga[c], p, dot);
-        }
-        dl[f * 2 * C + c] = dls;
+      const size_t o = ((size_t)b_ * T + min(f0 + f, T - 1)) * C + c;
+      const float s = strong[o];
+      const float p = sof_raw[o];
+      const float ys = has_ys ? y_strong[o] : 0.f;
+      const float es = has_es ? ema_strong[o] : 0.f;
+      const float es2 = has_es2 ? ema_strong2[o] : 0.f;
+      const float gx = has_gx ? g_strong_ext[o] : 0.f;
+      const float a = attention ? fminf(fmaxf(p, 1e-7f), 1.0f) : 1.0f;
+      float gs = gwk[c] * a / dn[c];
+      if (has_ys) {
+        gs += w_strong * bce_grad(s, ys) * inv_n_strong;
+        l_s += ok ? bce_val(s, ys) : 0.f;
       }
-      for (int c = 0; c < C; ++c) dl[f * 2 * C + C + c] = pa[c] * (ga[c] - dot);
+      if (has_es) {
+        const float d = s - es;
+        gs += w_cons_s * 2.f * d * inv_n_strong;
+        l_cs += ok ? d * d : 0.f;
+      }
+      if (has_es2) {
+        const float d = s - es2;
+        gs += w_cons_s2 * 2.f * d * inv_n_strong;
+        l_cs2 += ok ? d * d : 0.f;
+      }
+      if (has_gx) gs += gx;
+      float ga = 0.f;
+      if (attention && p >= 1e-7f && p <= 1.0f) ga = gwk[c] * (s - wk[c]) / dn[c];
+      dl[f * 2 * C + c] = ok ? gs * s * (1.f - s) : 0.f;
+      gaS[e] = ok ? ga : 0.f;
+      paS[e] = ok ? p : 0.f;
     }
     __syncthreads();
-    // dx[f][k]: 8 threads per frame, 32 columns each
-    {
-      const int f = tid >> 3, kg = tid & 7;
-      if (f0 + f < T) {
-        float* dxr = dx + ((size_t)b_ * T + f0 + f) * HD_K;
-        for (int kk = 0; kk < 32; ++kk) {
-          const int k = kg + 8 * kk;
-          float a = 0.f;
+    // softmax backward: dl[f][C + c] = p (ga - sum_c' ga p)
+    for (int e = tid; e < HD_FR * C; e += HD_THREADS) {
+      const int f = e / C;
+      float dot = 0.f;
 #pragma unroll
-          for (int c = 0; c < 2 * C; ++c) a = fmaf(dl[f * 2 * C + c], ws[c * (HD_K + 1) + k], a);
-          dxr[k] = a;
+      for (int cc = 0; cc < C; ++cc) dot = fmaf(gaS[f * C + cc], paS[f * C + cc], dot);
+      dl[f * 2 * C + C + (e - f * C)] = paS[e] * (gaS[e] - dot);
+    }
+    __syncthreads();
+    {
+      f32x16 dxa[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dxa[j][r] = 0.f;
+#pragma unroll 4
+      for (int st = 0; st < C; ++st) {   // class c = 2 st + lh
+        const float av = dl[li * 2 * C + 2 * st + lh];
+        const float* wr = ws + (2 * st + lh) * (HD_K + 1) + 64 * wave + li;
+        dxa[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wr[0], dxa[0], 0, 0, 0);
+        dxa[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wr[32], dxa[1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = hd_crow(r, lh);
+        if (f0 + f < T) {
+          float* dxr = dx + ((size_t)b_ * T + f0 + f) * HD_K + 64 * wave + li;
+          dxr[0] = dxa[0][r];
+          dxr[32] = dxa[1][r];
         }
       }
     }
-    // dW[c][k = tid] += sum_f dl[f][c] * x[f][k]
-    for (int f = 0; f < HD_FR; ++f) {
-      const float xv = xs[f * (HD_K + 1) + tid];
-#pragma unroll
-      for (int c = 0; c < 2 * C; ++c) dwacc[c] = fmaf(dl[f * 2 * C + c], xv, dwacc[c]);
+#pragma unroll 4
+    for (int st = 0; st < HD_FR / 2; ++st) {   // frame f = 2 st + lh (frames past T hold dl = 0)
+      const int f = 2 * st + lh;
+      const float a0 = dl[f * 2 * C + li], a1 = dl[f * 2 * C + min(32 + li, 2 * C - 1)];
+      const float* xr = xs + f * (HD_K + 1) + 64 * wave + li;
+      const float b0 = xr[0], b1 = xr[32];
+      dwa[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, dwa[0][0], 0, 0, 0);
+      dwa[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, dwa[0][1], 0, 0, 0);
+      dwa[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, dwa[1][0], 0, 0, 0);
+      dwa[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, dwa[1][1], 0, 0, 0);
     }
     if (tid < 2 * C)
       for (int f = 0; f < HD_FR; ++f) dbacc += dl[f * 2 * C + tid];
   }
 #pragma unroll
-  for (int c = 0; c < 2 * C; ++c) dw_part[(prow * 2 * C + c) * HD_K + tid] = dwacc[c];
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = 32 * mt + hd_crow(r, lh);
+        if (c < 2 * C) dw_part[(prow * 2 * C + c) * HD_K + 64 * wave + 32 * j + li] = dwa[mt][j][r];
+      }
   if (tid < 2 * C) db_part[prow * 2 * C + tid] = dbacc;
   // loss partials of this clip (plain sums; the host applies weights and 1/N)
+  // wave sums (fixed butterfly order), then the four waves' values in order: repeatable
   float vals[6] = {l_s, l_w, l_cs, l_cw, l_cs2, 0.f};
-  for (int i = 0; i < 6; ++i) {
-    __syncthreads();
-    lred[tid] = vals[i];
-    __syncthreads();
-    if (tid == 0) {
-      float s = 0.f;
-      for (int j = 0; j < HD_THREADS; ++j) s += lred[j];
-      loss_part[prow * 6 + i] = s;
-    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const float v = wave_sum(vals[i]);
+    if ((tid & 63) == 0) lred[(tid >> 6) * 8 + i] = v;
   }
+  __syncthreads();
+  if (tid < 6) loss_part[prow * 6 + tid] = tid < 5 ? ((lred[tid] + lred[8 + tid]) + lred[16 + tid]) + lred[24 + tid] : 0.f;
 }
 
 // Event post-processing of get_predictions (reference src/evaluation_measures.py:188-205): binarise at `threshold`, then
@@ -405,8 +478,11 @@ extern "C" int bsed_decode_write(const float* mask, const int* offsets, int B, i
 // time splits per clip: enough workgroups for ~4 per CU, whole 32-frame chunks each
 extern "C" int bsed_head_splits(int B, int T) {
   const int chunks = (T + HD_FR - 1) / HD_FR;
+  static const int forced = getenv("BSED_HEAD_SPLITS") ? atoi(getenv("BSED_HEAD_SPLITS")) : 0;   // A/B knob
+  if (forced > 0) return forced <= chunks ? forced : chunks;
   int S = 1;
-  while (S < 8 && (long)B * S < 1024 && S * 2 <= chunks) S *= 2;
+  // (B = 256: two splits -- 512 workgroups, one per CU at a time: 85-90 KB of LDS each; four were 15 % slower backward)
+  while (S < 8 && (long)B * S < 512 && S * 2 <= chunks) S *= 2;
   return S;
 }
 
@@ -418,7 +494,7 @@ extern "C" int bsed_head_fwd(const float* x, const float* w, const float* b, flo
   BSED_CHECK_ARG(S == 1 || part, "bsed_head_fwd: %d time splits need the (B,%d,2,C) scratch buffer", S, S);
   BSED_CHECK_ARG(B > 0 && T > 0, "bsed_head_fwd: bad shape");
   BSED_CHECK_ARG(K == HD_K && C == 20, "bsed_head_fwd: built for K=256, nclass=20 (got %d, %d)", K, C);
-  const size_t smem = (size_t)(2 * C * (HD_K + 1) + HD_FR * (HD_K + 1) + HD_FR * 2 * C + 2 * C + 2 * HD_FR * C) * 4;
+  const size_t smem = (size_t)(2 * C * (HD_K + 1) + HD_FR * (HD_K + 1) + HD_FR * 2 * C + 2 * C + 2 * HD_FR * 2 * C) * 4;
   static BsedLdsOnce once;
   BSED_HIP(bsed_max_lds(once, (const void*)head_fwd_kernel<20>));
   hipLaunchKernelGGL(head_fwd_kernel<20>, dim3(B, S), dim3(HD_THREADS), smem, (hipStream_t)stream, x, w, b, strong,
@@ -436,7 +512,7 @@ extern "C" int bsed_head_bwd(const BsedHeadBwdDesc* d, void* stream) {
                      d->loss_part, "bsed_head_bwd: null tensor");
   BSED_CHECK_ARG(d->B > 0 && d->T > 0 && d->K == HD_K && d->C == 20, "bsed_head_bwd: built for K=256, nclass=20");
   const int C = 20;
-  const size_t smem = (size_t)(2 * C * (HD_K + 1) + HD_FR * (HD_K + 1) + HD_FR * 2 * C + 3 * C + HD_THREADS) * 4;
+  const size_t smem = (size_t)(2 * C * (HD_K + 1) + HD_FR * (HD_K + 1) + HD_FR * 2 * C + 3 * C + HD_THREADS + 2 * HD_FR * C) * 4;
   static BsedLdsOnce once;
   BSED_HIP(bsed_max_lds(once, (const void*)head_bwd_kernel<20>));
   hipLaunchKernelGGL(head_bwd_kernel<20>, dim3(d->B, bsed_head_splits(d->B, d->T)), dim3(HD_THREADS), smem,
