@@ -411,7 +411,10 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
   for (int t = 0; t < NTAPS; ++t) toff[t] = (p.dh[t] * PW + p.dw[t]) * I3S_ROW;
   const int n = n0 + li;
   const bool nok = n < p.N;
-  const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+  float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+  // consumed HERE: otherwise the compiler's wait for this load sits in front of its first use inside the tile loop and
+  // runs every iteration -- as vmcnt(0), i.e. as a wait for the patch prefetch as well
+  asm volatile("" : "+v"(bias));
   float s0 = 0.f, s1 = 0.f;
   const int a_total = P.PP * C4;
   const int ntiles = p.NB * p.tilesH * p.tilesW;
@@ -424,6 +427,13 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
     ppr[u] = (pos * P.pw_magic) >> 20;
     ppc[u] = pos - ppr[u] * PW;
   }
+  // The patch prefetch is issued by inline assembly and waited for by hand.  Its loads (tile t + 1) are older than the
+  // epilogue stores of tile t, so the wait in front of the next LDS write may leave those stores in flight -- s_waitcnt
+  // vmcnt(#stores) -- but hipcc's own wait insertion gives vmcnt(0) at a loop head whatever the body looks like, and then
+  // every tile starts by draining its predecessor's stores (1-2 k cycles with three workgroups per CU to cover for it).
+  // The compiler does not know these are memory instructions: nothing may touch pv between issue() and patch_wait() --
+  // tools/asm_load_check.py verifies that on the listing.  Loads are branch-free: positions outside the map read a
+  // clamped address and become zeros at the LDS write.
   u32x4 pv[PV];
   auto issue = [&](int tile) {
     const int tw_i = tile % p.tilesW; const int r1 = tile / p.tilesW;
@@ -432,13 +442,27 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
 #pragma unroll
     for (int u = 0; u < PV; ++u) {
       const int e = tid + u * I3_THREADS;
-      const int gh = th_i * p.TH - p.hh + ppr[u], gw = tw_i * p.TW - p.hw + ppc[u];
-      const bool ok = e < a_total && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
-      pv[u] = ok ? *reinterpret_cast<const u32x4*>(inb + (((size_t)gh * p.W + gw) * p.in_pitch * (ABF ? 2 : 4)) + 16 * (e % C4))
-                 : u32x4{0u, 0u, 0u, 0u};
+      const int gh = min(max(th_i * p.TH - p.hh + ppr[u], 0), p.H - 1), gw = min(max(tw_i * p.TW - p.hw + ppc[u], 0), p.W - 1);
+      const char* a = inb + (((size_t)gh * p.W + gw) * p.in_pitch * (ABF ? 2 : 4)) + 16 * (e % C4);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pv[u]) : "v"(a) : "memory");
     }
   };
-  if ((int)blockIdx.x < ntiles) issue(blockIdx.x);
+  // all but the `keep` youngest vector-memory operations of the wave are done
+  auto patch_wait = [&](bool counted) {
+    constexpr int NST = NV == 16 ? 2 : 16;   // epilogue stores per lane and tile when nothing is masked
+    // (the counted wait is unconditional -- after a vmcnt(0) it is a no-op -- so that every path from a load to a use
+    //  passes through ONE wait instruction: simpler for the compiler's block layout and for the listing check)
+    if (!counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NST == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < PV; ++u) asm volatile("" : "+v"(pv[u]));
+  };
+  // every store of every tile of this workgroup is unmasked: whole tiles and whole channel groups
+  const bool allfull = p.H % p.TH == 0 && n0 + NV <= p.N;
+  // The wait sits at the END of a tile's iteration (after its stores have been issued), so the registers are valid data
+  // again before control reaches the loop's back edge: register copies the allocator places there are harmless.
+  if ((int)blockIdx.x < ntiles) { issue(blockIdx.x); patch_wait(false); }
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int tw_i = tile % p.tilesW; const int r1 = tile / p.tilesW;
@@ -449,11 +473,14 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
     for (int u = 0; u < PV; ++u) {
       const int e = tid + u * I3_THREADS;
       if (e < a_total) {
+        const int gh = th0 - p.hh + ppr[u], gw = tw0 - p.hw + ppc[u];
+        const bool inside = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+        const u32x4 pvu = inside ? pv[u] : u32x4{0u, 0u, 0u, 0u};
         if (ABF) {
-          *reinterpret_cast<u32x4*>(As + (e / C4) * I3S_ROW + 8 * (e % C4)) = pv[u];
+          *reinterpret_cast<u32x4*>(As + (e / C4) * I3S_ROW + 8 * (e % C4)) = pvu;
         } else {
           uint32_t h01, l01, h23, l23;
-          const f32x4 v = __builtin_bit_cast(f32x4, pv[u]);
+          const f32x4 v = __builtin_bit_cast(f32x4, pvu);
           bsed_split2(v[0], v[1], h01, l01);
           bsed_split2(v[2], v[3], h23, l23);
           unsigned short* dst = As + (e / C4) * I3S_ROW + 4 * (e % C4);
@@ -463,7 +490,7 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
       }
     }
     __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);  // next tile's patch: in flight during the MFMAs
+    issue(min(tile + (int)gridDim.x, ntiles - 1));  // next tile's patch: in flight during the MFMAs (the last: a dummy)
 
     f32x16 acc;
 #pragma unroll
@@ -505,8 +532,9 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
         const int mm = wave * 32 + pos;
         const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
         const f32x4 v = *reinterpret_cast<const f32x4*>(Es + pos * I3S_EROW + 4 * q);
-        if (gh < p.H && n0 + 4 * q < p.N)
-          act_st4<ABF>(p.out, (((size_t)nb * p.H + gh) * p.W + gw) * p.out_pitch + n0 + 4 * q, v);
+        const size_t o = (((size_t)nb * p.H + gh) * p.W + gw) * p.out_pitch + n0 + 4 * q;
+        if (allfull) act_st4<ABF>(p.out, o, v);   // (uniform: the unmasked form is branch-free)
+        else if (gh < p.H && n0 + 4 * q < p.N) act_st4<ABF>(p.out, o, v);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next tile's image is written
     } else {
@@ -519,21 +547,28 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
       char* ob = reinterpret_cast<char*>(p.out) + (((size_t)nb * p.H + th0) * p.W + tw0) * p.out_pitch * OSZ;
       const uint32_t voff = (uint32_t)(eoff(4 * lh) + n) * OSZ;
       const bool full = th0 + p.TH <= p.H;
+      auto put = [&](int rg, int q) {
+        const int mu = wu * 32 + 8 * rg;
+        const float v = acc[4 * rg + q] + bias;
+        char* dst = ob + (size_t)(uint32_t)(eoff(mu) + eoff(q)) * OSZ + voff;
+        if (ABF) *reinterpret_cast<__bf16*>(dst) = (__bf16)v;
+        else *reinterpret_cast<float*>(dst) = v;
+        if (STATS) { s0 += v; s1 = fmaf(v, v, s1); }
+      };
+      if (allfull) {   // uniform: sixteen unmasked stores, no branch
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg)
+        for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int mu = wu * 32 + 8 * rg;
-          const bool ok = nok && (full || th0 + ((mu + 4 * lh + q) >> P.lgTW) < p.H);
-          if (ok) {
-            const float v = acc[4 * rg + q] + bias;
-            char* dst = ob + (size_t)(uint32_t)(eoff(mu) + eoff(q)) * OSZ + voff;
-            if (ABF) *reinterpret_cast<__bf16*>(dst) = (__bf16)v;
-            else *reinterpret_cast<float*>(dst) = v;
-            if (STATS) { s0 += v; s1 = fmaf(v, v, s1); }
-          }
-        }
+          for (int q = 0; q < 4; ++q) put(rg, q);
+      } else {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (nok && (full || th0 + ((wu * 32 + 8 * rg + 4 * lh + q) >> P.lgTW) < p.H)) put(rg, q);
+      }
     }
+    patch_wait(allfull);   // the next tile's patch has landed; this tile's stores may still be in flight
   }
   if (STATS) {
     __syncthreads();
