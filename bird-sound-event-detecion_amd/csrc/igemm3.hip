@@ -464,6 +464,17 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
   // again before control reaches the loop's back edge: register copies the allocator places there are harmless.
   if ((int)blockIdx.x < ntiles) { issue(blockIdx.x); patch_wait(false); }
 
+  // WREG (the 32 -> 16 channel data gradient, 18 fragment pairs): the hi weight fragments live in registers for the whole
+  // kernel.  From LDS, every MFMA triple costs four 16-byte wave reads (two activation, two weight fragments): with
+  // three workgroups per CU the LDS array was the busiest unit of this instance (0.65, matrix pipe 0.50).
+  constexpr bool WREG = NV == 16 && KS == 2 && NTAPS == 9 && !STATS;
+  // (fp32 activations: only the hi fragments -- all 36 would leave two waves per SIMD: 0.52 vs 0.42 ms)
+  u32x4 wreg[WREG ? NTAPS * KS : 1];
+  if (WREG) {
+    __syncthreads();   // Wf is complete
+#pragma unroll
+    for (int i = 0; i < NTAPS * KS; ++i) wreg[i] = Wf[(2 * i + 0) * WL + wlane];
+  }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int tw_i = tile % p.tilesW; const int r1 = tile / p.tilesW;
     const int th_i = r1 % p.tilesH, nb = r1 / p.tilesH;
@@ -505,7 +516,7 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
       }
 #pragma unroll
       for (int t = 0; t < NTAPS; ++t) {
-        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, Wf[((t * KS + kk) * 2 + 0) * WL + wlane]);
+        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, WREG ? wreg[t * KS + kk] : Wf[((t * KS + kk) * 2 + 0) * WL + wlane]);
         if (!ABF) {
           const bf16x8 b_lo = __builtin_bit_cast(bf16x8, Wf[((t * KS + kk) * 2 + 1) * WL + wlane]);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[t], b_hi, acc, 0, 0, 0);
