@@ -140,6 +140,7 @@ SPLIT_KERNEL = re.compile(r"3[a-z]?_kernel")      # *3_kernel / *3n / *3p / *3s:
 MFMA_KERNEL = re.compile(r"^(igemm|wgrad|glu_fwd3|glu_bwd3|glu_bwd_fused|gru_fwd_mfma|gru_bwd_mfma|glu16|b0_fwd|b0_bwd)")
 ALGORITHMIC_MB_PER_CLIP = {22050: 128.9, 32000: 186.9}     # SURVEY.md 8(d), fp32 activations, mel stage included
 ALGORITHMIC_MB_PER_CLIP_BF16 = {22050: 65.1, 32000: 94.4}  # SURVEY.md 8(d), bf16 activations (--dtype bf16)
+B0_KERNEL = re.compile(r"^b0_(fwd|bwd)_kernel<")
 SINGLE_BF16 = re.compile(r"[<,] ?1>$")   # template instances of the split kernels whose last argument (ABF) is 1: ONE bf16 MFMA per product
 STEP_GFLOP_PER_CLIP = {22050: 7.63, 32000: 11.05}           # SURVEY.md 8(d), train step = fwd + 2 x bwd
 
@@ -150,6 +151,8 @@ def kernel_roofline(name, launches, total_ms, flops_total, bytes_total):
     and plain VALU kernels share the 157.3 TFLOP/s fp32 ceiling."""
     split = SPLIT_KERNEL.search(name) is not None
     single = split and SINGLE_BF16.search(name.strip()) is not None    # the bf16 throughput mode's instances
+    # ... and the first block's: b0_fwd / b0_bwd<.., 1> run their four 16 x 16 x 16 contractions as single bf16 MFMAs
+    single = single or (B0_KERNEL.search(name) is not None and SINGLE_BF16.search(name.strip()) is not None)
     peak_tf = PEAK_BF16_MFMA_TFLOPS if single else (PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS)
     avg_ms = total_ms / launches
     tflops = flops_total / (total_ms * 1e-3) / 1e12

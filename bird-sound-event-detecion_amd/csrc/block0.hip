@@ -45,6 +45,22 @@ __device__ __forceinline__ f32x4 b0_mm16(const float (&a)[4], float b0, float b1
   return c;
 }
 
+// bf16 mode (ABF instances): the same 16 x 16 x 16 contraction as ONE v_mfma_f32_16x16x16_bf16 -- operands rounded to bf16
+// (round to nearest even), fp32 accumulation; ~19 cycles instead of 4 x 32 (tools/probe/mfma16_probe.hip).  The lane layout
+// is the fp32 chain's: a lane's four values are k = 4 q .. 4 q + 3 of row / column p.
+typedef short b0_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ b0_s16x4 b0_pack4(float v0, float v1, float v2, float v3) {
+  const f32x2 a = {v0, v1}, b = {v2, v3};
+  const uint2 r = make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(a, bsed_bf16x2)),
+                             __builtin_bit_cast(uint32_t, __builtin_convertvector(b, bsed_bf16x2)));
+  return __builtin_bit_cast(b0_s16x4, r);
+}
+__device__ __forceinline__ f32x4 b0_mm16_bf(b0_s16x4 a, float b0, float b1, float b2, float b3, f32x4 c) {
+  b0_s16x4 b = b0_pack4(b0, b1, b2, b3);
+  asm volatile("s_nop 4" : "+v"(b), "+v"(c));
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
 // rows r0-1 .. r0+PH of image b at columns w-1, w, w+1 (zero outside the map): the inputs of PH stacked positions
 template <int PH>
 struct B0X { float v[PH + 2][3]; };
@@ -266,6 +282,24 @@ struct B0Conv {
 #pragma unroll
     for (int i = 0; i < 4; ++i) bias[i] = cb[4 * q + i];
   }
+  // bf16 mode: taps 4q .. 4q+3 as one packed operand (taps >= 9 carry weight 0 and read tap 8's window element)
+  b0_s16x4 aw16;
+  int off16[4];
+  __device__ __forceinline__ void init_bf(const float* __restrict__ cw, int p, int q) {
+    float w4[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int t = 4 * q + kk, tc = t < 9 ? t : 8;
+      w4[kk] = t < 9 ? cw[p * 9 + t] : 0.f;
+      off16[kk] = (tc / 3) * B0_WIN + (tc % 3) + p;
+    }
+    aw16 = b0_pack4(w4[0], w4[1], w4[2], w4[3]);
+  }
+  __device__ __forceinline__ f32x4 run_bf(const float* win, int dh) const {
+    const float b0 = win[dh * B0_WIN + off16[0]], b1 = win[dh * B0_WIN + off16[1]], b2 = win[dh * B0_WIN + off16[2]],
+                b3 = win[dh * B0_WIN + off16[3]];
+    return b0_mm16_bf(aw16, b0, b1, b2, b3, f32x4{bias[0], bias[1], bias[2], bias[3]});
+  }
   // y of the lane's position in window row dh (its four channels 4q .. 4q+3)
   __device__ __forceinline__ f32x4 run(const float* win, int dh) const {
     float b0 = win[dh * B0_WIN + off[0]], b1 = win[dh * B0_WIN + off[1]], b2 = win[dh * B0_WIN + off[2]];
@@ -297,9 +331,11 @@ __global__ __launch_bounds__(B0F_THREADS) void b0_fwd_kernel(
   float* win = wins[wave];
   B0Conv K;
   K.init(cw, cb, p, q);
+  if (ABF) K.init_bf(cw, p, q);
   float a1[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) a1[kk] = wg[p * C + 4 * q + kk];
+  const b0_s16x4 a1b = b0_pack4(a1[0], a1[1], a1[2], a1[3]);
   float sc[4], sh[4], bi[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { sc[i] = scale[4 * q + i]; sh[i] = shift[4 * q + i]; bi[i] = bg[4 * q + i]; }
@@ -329,11 +365,12 @@ __global__ __launch_bounds__(B0F_THREADS) void b0_fwd_kernel(
       const int h = hp * PH + dh;
       const size_t pos = ((size_t)b * H + h) * W + wc;
       const uint32_t pos32 = (uint32_t)((b * H + h) * W + wc);
-      const f32x4 y = K.run(win, dh);
+      const f32x4 y = ABF ? K.run_bf(win, dh) : K.run(win, dh);
       float xn[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) xn[i] = fmaf(y[i], sc[i], sh[i]);
-      const f32x4 lin = b0_mm16(a1, xn[0], xn[1], xn[2], xn[3], f32x4{0.f, 0.f, 0.f, 0.f});
+      const f32x4 lin = ABF ? b0_mm16_bf(a1b, xn[0], xn[1], xn[2], xn[3], f32x4{0.f, 0.f, 0.f, 0.f})
+                            : b0_mm16(a1, xn[0], xn[1], xn[2], xn[3], f32x4{0.f, 0.f, 0.f, 0.f});
       float dm[4];
       if (SMALL) {   // fewer than 2^32 elements: 32-bit counters (same masks)
         drop_mul2_32(pos32 * C + 4 * q, dkey, dthr, dscale, dm[0], dm[1]);
@@ -399,12 +436,14 @@ __global__ __launch_bounds__(B0B_THREADS, B0B_WPE) void b0_bwd_kernel(
   float* txn = tiles[wave][1];
   B0Conv K;
   K.init(cw, cb, p, q);
+  if (ABF) K.init_bf(cw, p, q);
   int xoff[9];   // the nine taps at the lane's own position (VALU Gx)
 #pragma unroll
   for (int t = 0; t < 9; ++t) xoff[t] = (t / 3) * B0_WIN + (t % 3) + p;
   float a1[4], a2[4];   // W[n = p][4q + kk]  and  W[4q + kk][c = p]
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) { a1[kk] = wg[p * C + 4 * q + kk]; a2[kk] = wg[(4 * q + kk) * C + p]; }
+  const b0_s16x4 a1b = b0_pack4(a1[0], a1[1], a1[2], a1[3]), a2b = b0_pack4(a2[0], a2[1], a2[2], a2[3]);
   float sc[4], sh[4], bi[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { sc[i] = scale[4 * q + i]; sh[i] = shift[4 * q + i]; bi[i] = bg[4 * q + i]; }
@@ -457,11 +496,12 @@ __global__ __launch_bounds__(B0B_THREADS, B0B_WPE) void b0_bwd_kernel(
       const int h = hp * PH + dh;
       const size_t pos = ((size_t)b * H + h) * W + min(w, W - 1);
       const uint32_t pos32 = (uint32_t)((b * H + h) * W + min(w, W - 1));
-      const f32x4 yv = K.run(win, dh);
+      const f32x4 yv = ABF ? K.run_bf(win, dh) : K.run(win, dh);
       float xn[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) xn[i] = fmaf(yv[i], sc[i], sh[i]);
-      const f32x4 lin = b0_mm16(a1, xn[0], xn[1], xn[2], xn[3], f32x4{0.f, 0.f, 0.f, 0.f});
+      const f32x4 lin = ABF ? b0_mm16_bf(a1b, xn[0], xn[1], xn[2], xn[3], f32x4{0.f, 0.f, 0.f, 0.f})
+                            : b0_mm16(a1, xn[0], xn[1], xn[2], xn[3], f32x4{0.f, 0.f, 0.f, 0.f});
       float dl[4], dm[4];
       f32x4 gt;
       if (SMALL) {
@@ -481,7 +521,8 @@ __global__ __launch_bounds__(B0B_THREADS, B0B_WPE) void b0_bwd_kernel(
       // operands of the dW contraction into the transpose tiles (row = position p, columns 4q .. 4q+3)
       *reinterpret_cast<float4*>(tdl + p * B0_TP + 4 * q) = make_float4(dl[0], dl[1], dl[2], dl[3]);
       *reinterpret_cast<float4*>(txn + p * B0_TP + 4 * q) = make_float4(xn[0], xn[1], xn[2], xn[3]);
-      const f32x4 g = b0_mm16(a2, dl[0], dl[1], dl[2], dl[3], gt);   // g = d_lin W + gate term (0 on idle columns)
+      // g = d_lin W + gate term (0 on idle columns)
+      const f32x4 g = ABF ? b0_mm16_bf(a2b, dl[0], dl[1], dl[2], dl[3], gt) : b0_mm16(a2, dl[0], dl[1], dl[2], dl[3], gt);
       float x9[9];
 #pragma unroll
       for (int t = 0; t < 9; ++t) x9[t] = win[dh * B0_WIN + xoff[t]];
@@ -499,8 +540,14 @@ __global__ __launch_bounds__(B0B_THREADS, B0B_WPE) void b0_bwd_kernel(
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 4" : "+v"(ta[0]), "+v"(ta[1]), "+v"(ta[2]), "+v"(ta[3]), "+v"(tb[0]),
                    "+v"(tb[1]), "+v"(tb[2]), "+v"(tb[3]), "+v"(dwacc) : : "memory");
+      if (ABF) {
+        b0_s16x4 ta4 = b0_pack4(ta[0], ta[1], ta[2], ta[3]), tb4 = b0_pack4(tb[0], tb[1], tb[2], tb[3]);
+        asm volatile("s_nop 4" : "+v"(ta4), "+v"(tb4), "+v"(dwacc));
+        dwacc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ta4, tb4, dwacc, 0, 0, 0);
+      } else {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) dwacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s], tb[s], dwacc, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) dwacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s], tb[s], dwacc, 0, 0, 0);
+      }
     }
   }
 
