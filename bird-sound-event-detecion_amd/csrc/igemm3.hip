@@ -434,6 +434,10 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
   // The compiler does not know these are memory instructions: nothing may touch pv between issue() and patch_wait() --
   // tools/asm_load_check.py verifies that on the listing.  Loads are branch-free: positions outside the map read a
   // clamped address and become zeros at the LDS write.
+  // HANDWAIT only in the 32-channel-output form: in the 16-channel form (its epilogue goes through an LDS image and
+  // needs more registers) the allocator moved in-flight registers around -- caught by the listing check, not by a test --
+  // and the instance did not gain anyway (its busiest unit is the LDS array); it keeps compiler-tracked loads.
+  constexpr bool HANDWAIT = NV == 32;
   u32x4 pv[PV];
   auto issue = [&](int tile) {
     const int tw_i = tile % p.tilesW; const int r1 = tile / p.tilesW;
@@ -442,26 +446,31 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
 #pragma unroll
     for (int u = 0; u < PV; ++u) {
       const int e = tid + u * I3_THREADS;
-      const int gh = min(max(th_i * p.TH - p.hh + ppr[u], 0), p.H - 1), gw = min(max(tw_i * p.TW - p.hw + ppc[u], 0), p.W - 1);
-      const char* a = inb + (((size_t)gh * p.W + gw) * p.in_pitch * (ABF ? 2 : 4)) + 16 * (e % C4);
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pv[u]) : "v"(a) : "memory");
+      if (HANDWAIT) {
+        const int gh = min(max(th_i * p.TH - p.hh + ppr[u], 0), p.H - 1), gw = min(max(tw_i * p.TW - p.hw + ppc[u], 0), p.W - 1);
+        const char* a = inb + (((size_t)gh * p.W + gw) * p.in_pitch * (ABF ? 2 : 4)) + 16 * (e % C4);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pv[u]) : "v"(a) : "memory");
+      } else {   // tracked by the compiler: its own waits apply
+        const int gh = th_i * p.TH - p.hh + ppr[u], gw = tw_i * p.TW - p.hw + ppc[u];
+        const bool ok = e < a_total && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+        pv[u] = ok ? *reinterpret_cast<const u32x4*>(inb + (((size_t)gh * p.W + gw) * p.in_pitch * (ABF ? 2 : 4)) + 16 * (e % C4))
+                   : u32x4{0u, 0u, 0u, 0u};
+      }
     }
   };
   // all but the `keep` youngest vector-memory operations of the wave are done
   auto patch_wait = [&](bool counted) {
-    constexpr int NST = NV == 16 ? 2 : 16;   // epilogue stores per lane and tile when nothing is masked
-    // (the counted wait is unconditional -- after a vmcnt(0) it is a no-op -- so that every path from a load to a use
-    //  passes through ONE wait instruction: simpler for the compiler's block layout and for the listing check)
+    if (!HANDWAIT) return;
+    constexpr int NST = 16;   // epilogue stores per lane and tile when nothing is masked
     if (!counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (NST == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 #pragma unroll
     for (int u = 0; u < PV; ++u) asm volatile("" : "+v"(pv[u]));
   };
   // every store of every tile of this workgroup is unmasked: whole tiles and whole channel groups
   const bool allfull = p.H % p.TH == 0 && n0 + NV <= p.N;
-  // The wait sits at the END of a tile's iteration (after its stores have been issued), so the registers are valid data
-  // again before control reaches the loop's back edge: register copies the allocator places there are harmless.
+  // The wait sits at the END of a tile's iteration (behind its stores, in the same branch arm), so the registers are valid
+  // data again before control reaches the loop's back edge: register copies the allocator places there are harmless.
   if ((int)blockIdx.x < ntiles) { issue(blockIdx.x); patch_wait(false); }
 
   // WREG (the 32 -> 16 channel data gradient, 18 fragment pairs): the hi weight fragments live in registers for the whole
@@ -485,7 +494,7 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
       const int e = tid + u * I3_THREADS;
       if (e < a_total) {
         const int gh = th0 - p.hh + ppr[u], gw = tw0 - p.hw + ppc[u];
-        const bool inside = gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+        const bool inside = !HANDWAIT || (gh >= 0 && gh < p.H && gw >= 0 && gw < p.W);   // (tracked loads come zeroed)
         const u32x4 pvu = inside ? pv[u] : u32x4{0u, 0u, 0u, 0u};
         if (ABF) {
           *reinterpret_cast<u32x4*>(As + (e / C4) * I3S_ROW + 8 * (e % C4)) = pvu;
@@ -501,7 +510,9 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
       }
     }
     __syncthreads();
-    issue(min(tile + (int)gridDim.x, ntiles - 1));  // next tile's patch: in flight during the MFMAs (the last: a dummy)
+    // next tile's patch: in flight during the MFMAs (hand-waited form: the last tile requests a dummy, no branch)
+    if (HANDWAIT) issue(min(tile + (int)gridDim.x, ntiles - 1));
+    else if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
 
     f32x16 acc;
 #pragma unroll
@@ -543,9 +554,8 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
         const int mm = wave * 32 + pos;
         const int gh = th0 + (mm >> P.lgTW), gw = tw0 + (mm & (p.TW - 1));
         const f32x4 v = *reinterpret_cast<const f32x4*>(Es + pos * I3S_EROW + 4 * q);
-        const size_t o = (((size_t)nb * p.H + gh) * p.W + gw) * p.out_pitch + n0 + 4 * q;
-        if (allfull) act_st4<ABF>(p.out, o, v);   // (uniform: the unmasked form is branch-free)
-        else if (gh < p.H && n0 + 4 * q < p.N) act_st4<ABF>(p.out, o, v);
+        if (gh < p.H && n0 + 4 * q < p.N)
+          act_st4<ABF>(p.out, (((size_t)nb * p.H + gh) * p.W + gw) * p.out_pitch + n0 + 4 * q, v);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next tile's image is written
     } else {
@@ -566,20 +576,23 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
         else *reinterpret_cast<float*>(dst) = v;
         if (STATS) { s0 += v; s1 = fmaf(v, v, s1); }
       };
+      // the stores and the wait for the next tile's patch share an arm: the counted wait is only reached behind the
+      // unmasked stores it counts (tools/asm_load_check.py checks the count on the listing)
       if (allfull) {   // uniform: sixteen unmasked stores, no branch
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
           for (int q = 0; q < 4; ++q) put(rg, q);
+        patch_wait(true);
       } else {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             if (nok && (full || th0 + ((wu * 32 + 8 * rg + 4 * lh + q) >> P.lgTW) < p.H)) put(rg, q);
+        patch_wait(false);
       }
     }
-    patch_wait(allfull);   // the next tile's patch has landed; this tile's stores may still be in flight
   }
   if (STATS) {
     __syncthreads();

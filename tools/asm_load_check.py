@@ -5,7 +5,10 @@ The kernel issues its patch prefetch by inline assembly (`global_load_dwordx4` i
 by hand (`s_waitcnt vmcnt(N)` inside ;;#ASMSTART): the compiler does not know the destination registers are in flight, so
 NOTHING may read or write them between a load and the next hand-written wait -- a register copy the allocator slips
 in there would copy stale data.  For every kernel of the listing this walks every path from an inline-asm load until it
-meets an inline-asm wait, along fall-through and branch edges, and reports any instruction touching a pending register.
+meets the counted inline-asm wait, along fall-through and branch edges, and reports (1) any instruction touching a pending
+register and (2) any path on which the counted wait `vmcnt(N)` is reached with fewer than N younger vector-memory
+instructions and without the full `vmcnt(0)` wait of the masked-store path in front of it (the wait would then prove
+nothing: a masked store, or a spill the compiler added, changes the count).
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S csrc/igemm3.hip -o /tmp/i3.s
     python tools/asm_load_check.py /tmp/i3.s [kernel-name-substring]"""
@@ -40,27 +43,40 @@ def check(name, lines):
         ins.append((t.split(";")[0].strip(), in_app))
     starts = [i for i, (t, a) in enumerate(ins) if a and t.startswith("global_load_dwordx4")]
     bad, seen = [], set()
-    work = [(i + 1, frozenset(regs_of(ins[i][0].split(",")[0]))) for i in starts]
+    # state: (next instruction, pending registers, younger vector-memory instructions (capped), passed a hand vmcnt(0))
+    work = [(i + 1, frozenset(regs_of(ins[i][0].split(",")[0])), 0, False) for i in starts]
     while work:
-        i, pend = work.pop()
+        i, pend, young, drained = work.pop()
         while i < len(ins):
-            if (i, pend) in seen:
+            if (i, pend, young, drained) in seen:
                 break
-            seen.add((i, pend))
+            seen.add((i, pend, young, drained))
             t, a = ins[i]
-            if a and t.startswith("s_waitcnt") and "vmcnt" in t:
-                break                                   # the hand-written wait: path ends
-            if a and t.startswith("global_load_dwordx4"):
+            op = t.split()[0]
+            if a and op == "s_waitcnt" and "vmcnt" in t:
+                n = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
+                if n == 0:
+                    break                               # everything has landed: path ends
+                else:
+                    # the counted wait: it only proves the load done if at least n vector-memory instructions are
+                    # younger than it (fewer -- a masked store path, a spill the compiler added -- and it proves nothing)
+                    if not drained and young < n:
+                        bad.append((i, f"{t}   <- only {young} younger vector-memory instructions on this path"))
+                    break
+                i += 1
+                continue
+            if re.match(r"(global|scratch|buffer|flat)_", op):
+                young = min(young + 1, 64)
+            if a and op == "global_load_dwordx4":
                 pend = pend | frozenset(regs_of(t.split(",")[0]))
             elif regs_of(t) & pend:
                 bad.append((i, t))
-            op = t.split()[0]
             if op == "s_endpgm":
                 break
             if op.startswith("s_cbranch") or op == "s_branch":
                 tgt = t.split()[-1]
                 if tgt in labels:
-                    work.append((labels[tgt], pend))
+                    work.append((labels[tgt], pend, young, drained))
                 if op == "s_branch":
                     break
             i += 1
