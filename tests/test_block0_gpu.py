@@ -156,3 +156,38 @@ def test_fused_block0_gradients_vs_oracle(conv_mode):
                                ocrnn.cnn.cnn.batchnorm0.running_var.numpy(), rtol=2e-4)
     np.testing.assert_allclose(fused.P("cnn.batchnorm0.running_mean").cpu().numpy(),
                                ocrnn.cnn.cnn.batchnorm0.running_mean.numpy(), rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,H,pool", [(2, 64, (2, 2)), (3, 65, (2, 2)), (2, 40, (1, 2))])
+def test_block0_bf16_instances_match_their_fp32_twins(B, H, pool):
+    """bf16 mode (conv_mode = "bf16"): b0_fwd / b0_bwd<.., 1> take / return bf16 pooled tensors and run their four
+    16 x 16 x 16 contractions per position as single v_mfma_f32_16x16x16_bf16 (operands rounded to bf16, fp32
+    accumulation) -- against the fp32 instances (exact-fp32 v_mfma_f32_16x16x4_f32) on the same inputs, same dropout
+    masks.  Bars: forward 1e-2 relative L2 (three chained bf16 roundings of 2^-9 each; measured 3.3e-3 .. 4.1e-3), every partial
+    sum of the backward pass 2e-2 of its fp32 twin's norm (measured <= 5.8e-3)."""
+    from bsed_amd import ops
+    W, C = 128, 16
+    rng = np.random.default_rng(5 * H + B)
+    x = torch.from_numpy(seeded.db_like_input(9, B, H)).cuda().reshape(B, H, W).contiguous()
+    cw = torch.from_numpy((rng.standard_normal((C, 9)) * 0.3).astype(np.float32)).cuda()
+    cb = torch.from_numpy((rng.standard_normal(C) * 0.1).astype(np.float32)).cuda()
+    scale = torch.from_numpy(rng.uniform(0.02, 0.06, C).astype(np.float32)).cuda()     # dB-scale inputs: y ~ 20
+    shift = torch.from_numpy((rng.standard_normal(C) * 0.3).astype(np.float32)).cuda()
+    wg = torch.from_numpy((rng.standard_normal((C, C)) * 0.3).astype(np.float32)).cuda()
+    bg = torch.from_numpy((rng.standard_normal(C) * 0.1).astype(np.float32)).cuda()
+    ph, pw = pool
+    outs = {dt: ops.block0_fwd(x, cw, cb, scale, shift, wg, bg, B, H, W, pool, 0.5, 100, 4242, out_dtype=dt)
+            for dt in (torch.float32, torch.bfloat16)}
+    ref, got = outs[torch.float32], outs[torch.bfloat16].float()
+    assert float((got - ref).norm() / ref.norm()) < 1e-2
+    assert float(ref.abs().max()) > 0.1            # the comparison is not between two zero tensors
+    dpool = torch.from_numpy(rng.standard_normal((B, H // ph, W // pw, C)).astype(np.float32)).cuda() * 1e-2
+    parts = {}
+    for dt in (torch.float32, torch.bfloat16):
+        parts[dt] = ops.block0_bwd(x, cw, cb, scale, shift, wg, bg, dpool.to(dt), B, H, W, pool, 0.5, 100, 4242)
+    # the fp32 twin is fed the SAME (bf16-rounded) upstream gradient, so only the contraction arithmetic differs
+    parts[torch.float32] = ops.block0_bwd(x, cw, cb, scale, shift, wg, bg, dpool.to(torch.bfloat16).float(), B, H, W,
+                                          pool, 0.5, 100, 4242)
+    for name, a, b in zip(("dW_glu", "db_glu", "bn sums", "Gx"), parts[torch.bfloat16][:4], parts[torch.float32][:4]):
+        a, b = a.double().sum(0), b.double().sum(0)
+        assert float((a - b).norm()) < 2e-2 * float(b.norm()) + 1e-9, (name, float((a - b).norm() / b.norm()))
