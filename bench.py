@@ -491,7 +491,8 @@ def main():
         # passes, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for the profiled workload
         try:
             if args.mode == "crnn" and B == 256 and args.sr == 22050 and args.seconds == 10.0:
-                for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                for fn in (("r03_pmc_traffic_bf16.json",) if args.dtype == "bf16" else ()) + \
+                          ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                     path = os.path.join(ROOT, "profiles", fn)
                     if not os.path.exists(path):
                         continue
