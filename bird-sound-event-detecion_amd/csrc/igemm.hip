@@ -881,9 +881,10 @@ __host__ __device__ constexpr W3Geo w3_geo(int g) {
        : g == 3 ? W3Geo{32, 4, 18, 180, 2}     // 32 -> 64, 216 x 32
        : g == 4 ? W3Geo{64, 2, 6, 204, 1}      // 128 -> 128, 216 x 4
        : g == 5 ? W3Geo{32, 1, 4, 264, 2}      // 128 -> 128, 216 x 2
+       : g == 6 ? W3Geo{32, 4, 18, 180, 1}     // 16 -> 32 (two taps per MFMA tile; also 32 -> 32), 432 x 64
                 : W3Geo{0, 0, 0, 0, 0};
 }
-#define W3_NGEO 5
+#define W3_NGEO 6
 
 // Diagnostic build (-DW3P_STAMP, tools/build_variant.sh + tools/wgrad_stamp.py): s_memtime stamps of the fourth tile period
 // of every workgroup -- slots 0..3 producer wave 4 (period start, loads landed, conversions + refills issued, barrier
@@ -1844,6 +1845,7 @@ static int launch_wgrad3p(const WgradParams& P, dim3 grid, size_t smem, hipStrea
   if (MAXS == 5 && g == 3) return launch_wgrad3p_geo<5, 3>(P, grid, smem, s);
   if (MAXS == 5 && g == 4) return launch_wgrad3p_geo<5, 4>(P, grid, smem, s);
   if (MAXS == 5 && g == 5) return launch_wgrad3p_geo<5, 5>(P, grid, smem, s);
+  if (MAXS == 3 && g == 6) return launch_wgrad3p_geo<3, 6>(P, grid, smem, s);
   return launch_wgrad3p_geo<MAXS, 0>(P, grid, smem, s);
 }
 
@@ -1851,11 +1853,12 @@ static int launch_wgrad3p(const WgradParams& P, dim3 grid, size_t smem, hipStrea
 // its register arrays; everything else (1-tap forms, tall narrow patches) stays on wgrad3_kernel
 static bool wgrad3_pipelined(const WgradParams& P, size_t smem) {
   const int nitems = (P.pack2 ? (P.d.ntaps + 1) / 2 : P.d.ntaps) * P.nct * P.ntw;
-  // fewest (tap, chunk) items the pipelined kernel takes.  The 16 -> 32 channel layer (5 items: two taps per MFMA tile)
-  // is at the HBM rate in wgrad3_kernel with fp32 activations (0.69 ms vs 0.78 ms pipelined) but not with bf16 ones,
-  // where the pipelined producers' 16-byte pieces win (0.65 -> 0.41 ms).  BSED_WGRAD3_PIPE_MIN: A/B knob
+  // fewest (tap, chunk) items the pipelined kernel takes: 4, i.e. the 16 -> 32 channel layer (5 items: two taps per MFMA
+  // tile) included.  With run-time geometry the pipelined kernel lost to wgrad3_kernel there with fp32 activations (0.78
+  // vs 0.69 ms; bf16: 0.41 vs 0.65); with the layer's geometry compiled in (w3_geo(6)) it wins in both modes: 0.60 ms
+  // fp32, 0.28 ms bf16.  BSED_WGRAD3_PIPE_MIN: A/B knob (8 = the old choice)
   static const int pipe_env = getenv("BSED_WGRAD3_PIPE_MIN") ? atoi(getenv("BSED_WGRAD3_PIPE_MIN")) : 0;
-  const int pipe_min = pipe_env > 0 ? pipe_env : (P.d.act_bf16 ? 4 : 8);
+  const int pipe_min = pipe_env > 0 ? pipe_env : 4;
   static const bool onetap_pipe = getenv("BSED_WGRAD3_1TAP_PIPE") && getenv("BSED_WGRAD3_1TAP_PIPE")[0] == '1';
   if (P.d.ntaps == 1 && !onetap_pipe) return false;
   return nitems > (P.d.ntaps == 1 ? 3 : pipe_min) &&
@@ -1901,7 +1904,7 @@ extern "C" int bsed_wgrad3_variant(const BsedWgradDesc* desc) {
   const int v = wgrad_variant(P);
   if (wgrad3_pipelined(P, smem)) {  // NW field 1 = wgrad3p_kernel<MAXS, GEO>, GEO in bits 8..11
     const int maxs = v / 16 <= 3 ? 3 : (v / 16 <= 5 ? 5 : 9), g = getenv("BSED_WGRAD3_NOGEO") ? 0 : wgrad3p_geo(P);
-    const bool built = (maxs == 9 && (g == 1 || g == 2)) || (maxs == 5 && g >= 3 && g <= 5);
+    const bool built = (maxs == 9 && (g == 1 || g == 2)) || (maxs == 5 && g >= 3 && g <= 5) || (maxs == 3 && g == 6);
     return maxs * 16 + 1 + ((built ? g : 0) << 8);
   }
   return v | (((v % 16) % (P.nct * P.ntw) == 0) ? 1 << 12 : 0);  // bit 12 = the BS template argument
