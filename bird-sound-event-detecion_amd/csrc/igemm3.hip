@@ -477,13 +477,28 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
   // kernel.  From LDS, every MFMA triple costs four 16-byte wave reads (two activation, two weight fragments): with
   // three workgroups per CU the LDS array was the busiest unit of this instance (0.65, matrix pipe 0.50).
   constexpr bool WREG = NV == 16 && KS == 2 && NTAPS == 9 && !STATS;
-  // (fp32 activations: only the hi fragments -- all 36 would leave two waves per SIMD: 0.52 vs 0.42 ms)
-  u32x4 wreg[WREG ? NTAPS * KS : 1];
+  // ... and that instance contracts on v_mfma_f32_16x16x32_bf16: a 16-column tile is exactly its output (the 32 x 32 form
+  // computes 16 columns that do not exist), and K = 32 is exactly its input channels: per tap 2 row tiles x 3 MFMAs of
+  // ~16 cycles instead of 2 k steps x 3 MFMAs of 32 cycles, one weight fragment per tap instead of two (9 registers x 4
+  // for the hi parts).  Lane (i = lane & 15, kg = lane >> 4): row i of the tile, channels 8 kg .. 8 kg + 7; the weight
+  // table's 32 x 32 x 16 fragments (k step kg >> 1, half kg & 1) hold just those values.
+  constexpr bool M16 = WREG;
+  const int li16 = lane & 15, kg = lane >> 4;
+  int abase16[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int m16 = wave * 32 + 16 * rt + li16;
+    abase16[rt] = (((m16 >> P.lgTW) + p.hh) * PW + (m16 & (p.TW - 1)) + p.hw) * I3S_ROW + 8 * kg;
+  }
+  const int wfrag16 = ((kg >> 1) * 2) * WL + li16 + 16 * (kg & 1);   // + (t * KS * 2 + hl) * WL
+  // (fp32 activations: only the hi fragments in registers)
+  u32x4 wreg[WREG ? NTAPS : 1];
   if (WREG) {
     __syncthreads();   // Wf is complete
 #pragma unroll
-    for (int i = 0; i < NTAPS * KS; ++i) wreg[i] = Wf[(2 * i + 0) * WL + wlane];
+    for (int t = 0; t < NTAPS; ++t) wreg[t] = Wf[(t * KS * 2 + 0) * WL + wfrag16];
   }
+  const float bias16 = (M16 && p.bias && n0 + li16 < p.N) ? p.bias[n0 + li16] : 0.f;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int tw_i = tile % p.tilesW; const int r1 = tile / p.tilesW;
     const int th_i = r1 % p.tilesH, nb = r1 / p.tilesH;
@@ -515,8 +530,30 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
     else if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
 
     f32x16 acc;
+    f32x4 acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if constexpr (M16) {
+#pragma unroll
+      for (int t = 0; t < NTAPS; ++t) {
+        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, wreg[t]);
+        bf16x8 a_hi[2], a_lo[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          a_hi[rt] = *reinterpret_cast<const bf16x8*>(As + abase16[rt] + toff[t]);
+          if (!ABF) a_lo[rt] = *reinterpret_cast<const bf16x8*>(As + abase16[rt] + toff[t] + CINK);
+        }
+        if (!ABF) {
+          const bf16x8 b_lo = __builtin_bit_cast(bf16x8, Wf[(t * KS * 2 + 1) * WL + wfrag16]);
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) acc16[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[rt], b_hi, acc16[rt], 0, 0, 0);
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) acc16[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[rt], b_lo, acc16[rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) acc16[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[rt], b_hi, acc16[rt], 0, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       bf16x8 a_hi[NTAPS], a_lo[NTAPS];
@@ -527,7 +564,7 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
       }
 #pragma unroll
       for (int t = 0; t < NTAPS; ++t) {
-        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, WREG ? wreg[t * KS + kk] : Wf[((t * KS + kk) * 2 + 0) * WL + wlane]);
+        const bf16x8 b_hi = __builtin_bit_cast(bf16x8, Wf[((t * KS + kk) * 2 + 0) * WL + wlane]);
         if (!ABF) {
           const bf16x8 b_lo = __builtin_bit_cast(bf16x8, Wf[((t * KS + kk) * 2 + 1) * WL + wlane]);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[t], b_hi, acc, 0, 0, 0);
@@ -537,6 +574,13 @@ __global__ __launch_bounds__(I3_THREADS) void igemm3s_kernel(const Igemm3Params 
       }
     }
     if (NV == 16) {
+      if constexpr (M16) {
+        // result fragment of the 16 x 16 tile: column li16, rows 4 kg + r
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Es[(16 * rt + 4 * kg + r) * I3S_EROW + li16] = acc16[rt][r] + bias16;
+      } else
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = crow3(r, lh);
