@@ -141,7 +141,20 @@ MFMA_KERNEL = re.compile(r"^(igemm|wgrad|glu_fwd3|glu_bwd3|glu_bwd_fused|gru_fwd
 ALGORITHMIC_MB_PER_CLIP = {22050: 128.9, 32000: 186.9}     # SURVEY.md 8(d), fp32 activations, mel stage included
 ALGORITHMIC_MB_PER_CLIP_BF16 = {22050: 65.1, 32000: 94.4}  # SURVEY.md 8(d), bf16 activations (--dtype bf16)
 B0_KERNEL = re.compile(r"^b0_(fwd|bwd)_kernel<")
-SINGLE_BF16 = re.compile(r"[<,] ?1>$")   # template instances of the split kernels whose last argument (ABF) is 1: ONE bf16 MFMA per product
+# template instances of the split kernels whose ABF argument is 1: ONE bf16 MFMA per product.  ABF is the last argument,
+# except in igemm3n_kernel<NWN, MW, STATS, PV, NT9, WPE, ABF[, SH]> (an eighth argument SH = 1 marks the 16 x 16 x 32 form)
+class _SingleBf16:
+    _last = re.compile(r"[<,] ?1>$")
+
+    def search(self, name):
+        m = re.match(r"^igemm3n_kernel<(.*)>$", name)
+        if m:
+            a = [t.strip() for t in m.group(1).split(",")]
+            return True if len(a) >= 7 and a[6] == "1" else None
+        return self._last.search(name)
+
+
+SINGLE_BF16 = _SingleBf16()
 STEP_GFLOP_PER_CLIP = {22050: 7.63, 32000: 11.05}           # SURVEY.md 8(d), train step = fwd + 2 x bwd
 
 

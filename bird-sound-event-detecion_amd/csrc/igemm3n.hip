@@ -19,6 +19,7 @@
 #include "bsed_common.h"
 #include "../../include/bsed.h"
 #include <algorithm>
+#include <atomic>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -62,7 +63,11 @@ __device__ __forceinline__ int crow3n(int r, int lh) { return (r & 3) + 8 * (r >
 // ABF = 1: the "bf16" throughput mode (BASELINE configs[1-2]): input AND output activations are bf16 in HBM, ONE bf16
 // MFMA per product (the hi halves of the same weight table), fp32 accumulation, bias and BatchNorm sums; the patch
 // goes to LDS as it arrives (rows of 32 bf16 + 8 pad = 80 B: 20 r mod 64 hits 16 distinct 4-bank groups).
-template <int NWN, int MW, int STATS, int PV, int NT9, int WPE, int ABF>
+// SH = 1: the same contraction on v_mfma_f32_16x16x32_bf16 tiles (a 32-row block = two row tiles, a wave's 32 channels =
+// two column tiles, K = 32 = one chunk per MFMA): same MFMA cycles and LDS reads per step, twice the MFMA instructions;
+// the shape holds a higher clock under load (MI355X_MICROARCH.md: ~1.12-1.15x the FLOP/s of the 32 x 32 x 16 loop).
+// The sums run over K in a different order (32 per MFMA instead of 2 x 16): results agree with SH = 0 to rounding.
+template <int NWN, int MW, int STATS, int PV, int NT9, int WPE, int ABF, int SH = 0>
 __global__ __launch_bounds__(64 * NWN * MW) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void igemm3n_kernel(const Igemm3nParams P) {
   constexpr int RB = 4 / MW, NTH = 64 * NWN * MW;
@@ -113,6 +118,21 @@ void igemm3n_kernel(const Igemm3nParams P) {
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+  // SH = 1: lane (li16 = row of the 16-row tile / column of the 16-column tile, kg = 8-channel group of the chunk)
+  const int li16 = lane & 15, kg = lane >> 4;
+  int abase16[SH ? RB : 1][2];
+  f32x4 acc16[SH ? RB : 1][2][2];   // [row block][row tile][column tile]
+  if (SH) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int m = (wm * RB + rb) * 32 + 16 * h + li16;
+        abase16[rb][h] = (((m >> P.lgTW) + p.hh) * PW + (m & (p.TW - 1)) + p.hw) * ROW + 8 * kg;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc16[rb][h][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  }
 
   // 16-byte units of the input image: 4 fp32 / 8 bf16 channels; poff counts them
   const u32x4* inb = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.in) +
@@ -139,12 +159,24 @@ void igemm3n_kernel(const Igemm3nParams P) {
   const int n = n0 + 32 * wn + li;
   const bool nok = n < p.N;
   const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+  // SH = 1: the lane's two channels (one per column tile)
+  const int n16 = n0 + 32 * wn + li16;
+  float bias16[2] = {0.f, 0.f};
+  if (SH && p.bias) {
+    if (n16 < p.N) bias16[0] = p.bias[n16];
+    if (n16 + 16 < p.N) bias16[1] = p.bias[n16 + 16];
+  }
 
   // this wave's weight fragments: table[jn][tap][k16][hi|lo][lane] of 16-byte elements (bsed_pack_weight3s layout)
-  const u32x4* wb = reinterpret_cast<const u32x4*>(p.w) + ((size_t)(n0 / 32 + wn) * ntaps * KS) * 128 + lane;
-  u32x4 bq[NF];   // the current step's fragments: [k half][hi | lo]  (ABF: [k half], hi only)
+  // SH = 1: column tile ct of the wave's 32 channels; the lane's eight k values (8 kg ..) of column 16 ct + li16 sit in
+  // the table's 32 x 32 x 16 fragment of k step kg >> 1 at lane (li = 16 ct + li16, lh = kg & 1): fragment index
+  // f = [ct][hi | lo] (ABF: [ct]) at offset ((kg >> 1) * 2 + hl) * 64 + 16 ct from a per-lane base
+  const u32x4* wb = reinterpret_cast<const u32x4*>(p.w) + ((size_t)(n0 / 32 + wn) * ntaps * KS) * 128 +
+                    (SH ? (kg >> 1) * 128 + (kg & 1) * 32 + li16 : lane);
+  auto foff = [&](int f) { return SH ? (ABF ? 0 : (f & 1)) * 64 + 16 * (ABF ? f : f >> 1) : (ABF ? 2 * f : f) * 64; };
+  u32x4 bq[NF];   // the current step's fragments: [k half][hi | lo]  (ABF: [k half], hi only); SH: [column tile][hi | lo]
 #pragma unroll
-  for (int f = 0; f < NF; ++f) bq[f] = wb[(ABF ? 2 * f : f) * 64];
+  for (int f = 0; f < NF; ++f) bq[f] = wb[foff(f)];
 
   // piece u of the prefetched patch chunk -> LDS (split into bf16 hi / lo; padding positions become zeros)
   auto write_piece = [&](int u, unsigned short* dstbuf) {
@@ -199,7 +231,7 @@ void igemm3n_kernel(const Igemm3nParams P) {
       const u32x4* wn_ = wb + (size_t)(ntap * KS + 2 * nch) * 128;
       u32x4 bn[NF];
 #pragma unroll
-      for (int f = 0; f < NF; ++f) bn[f] = wn_[(ABF ? 2 * f : f) * 64];
+      for (int f = 0; f < NF; ++f) bn[f] = wn_[foff(f)];
       // (hipcc sinks these loads to just before their first use -- a step later -- to save registers, which exposes
       //  the L2 latency twice per step; the scheduling fence below keeps them ahead of this step's reads and MFMAs)
       if (EARLYW && more) {
@@ -216,6 +248,30 @@ void igemm3n_kernel(const Igemm3nParams P) {
           if (tap == (6 * u) / PV + 3) write_piece(u, An);
       }
       const int toff = (p.dh[tap] * PW + p.dw[tap]) * ROW;
+      if constexpr (SH) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          bf16x8 a_hi[2], a_lo[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            a_hi[h] = *reinterpret_cast<const bf16x8*>(As + abase16[rb][h] + toff);
+            if (!ABF) a_lo[h] = *reinterpret_cast<const bf16x8*>(As + abase16[rb][h] + toff + 32);
+          }
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            const bf16x8 b_hi = __builtin_bit_cast(bf16x8, bq[ABF ? ct : 2 * ct]);
+            if (!ABF) {
+              const bf16x8 b_lo = __builtin_bit_cast(bf16x8, bq[ABF ? ct : 2 * ct + 1]);
+#pragma unroll
+              for (int h = 0; h < 2; ++h) acc16[rb][h][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[h], b_hi, acc16[rb][h][ct], 0, 0, 0);
+#pragma unroll
+              for (int h = 0; h < 2; ++h) acc16[rb][h][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[h], b_lo, acc16[rb][h][ct], 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc16[rb][h][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[h], b_hi, acc16[rb][h][ct], 0, 0, 0);
+          }
+        }
+      } else
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8 a_hi[RB], a_lo[RB];
@@ -269,7 +325,48 @@ void igemm3n_kernel(const Igemm3nParams P) {
     else *reinterpret_cast<float*>(dst) = v;
   };
   float s0 = 0.f, s1 = 0.f;
-  if (full) {
+  if constexpr (SH) {
+    // result fragment of a 16 x 16 tile: column li16, rows 4 kg + r.  Position m = (32 (wm RB + rb) + 16 h) [uniform]
+    // + 4 kg [lane] + r: three disjoint bit ranges again -- a scalar base per store, one per-lane byte offset
+    const uint32_t voff16 = (uint32_t)(eoff(4 * kg) + n16) * OSZ;
+    float t0[2] = {0.f, 0.f}, t1[2] = {0.f, 0.f};
+    auto emit = [&](auto guarded_c) {
+      constexpr bool guarded = decltype(guarded_c)::value;   // interior tiles store unmasked: no per-element test
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int mu = (wm * RB + rb) * 32 + 16 * h;
+            char* sb = ob + (size_t)(uint32_t)(eoff(mu) + eoff(r)) * OSZ;
+            const int mm = mu + 4 * kg + r;
+            const bool pok = !guarded || (th0 + (mm >> P.lgTW) < vh && tw0 + (mm & (p.TW - 1)) < vw);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              const float v = acc16[rb][h][ct][r] + bias16[ct];
+              if (!guarded || (pok && n16 + 16 * ct < p.N)) {
+                put(sb + voff16 + 16 * ct * OSZ, v);
+                if (STATS) { t0[ct] += v; t1[ct] = fmaf(v, v, t1[ct]); }
+              }
+            }
+          }
+    };
+    if (full) emit(std::false_type{}); else emit(std::true_type{});
+    if (STATS) {
+      // the four row groups (kg) of a column: lanes li16, li16 + 16, + 32, + 48
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        float a = t0[ct] + __shfl_xor(t0[ct], 16, 64), b = t1[ct] + __shfl_xor(t1[ct], 16, 64);
+        a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+        if (kg == 0 && n16 + 16 * ct < p.N) {
+          const size_t row = ((size_t)(nb * p.tilesH + th_i) * p.tilesW + tw_i) * MW + wm;
+          p.stats[(row * 2 + 0) * p.N + n16 + 16 * ct] = a;
+          p.stats[(row * 2 + 1) * p.N + n16 + 16 * ct] = b;
+        }
+      }
+    }
+  } else if (full) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -299,7 +396,7 @@ void igemm3n_kernel(const Igemm3nParams P) {
         }
       }
   }
-  if (STATS) {
+  if (STATS && !SH) {
     const float a = s0 + __shfl_xor(s0, 32, 64), b = s1 + __shfl_xor(s1, 32, 64);
     if (lh == 0 && nok) {
       // row (tile, wm) of the partial-sum table; the tile index here is the LOGICAL one (any fixed order will do)
@@ -316,8 +413,30 @@ void igemm3n_kernel(const Igemm3nParams P) {
 #endif
 }
 
+// MFMA shape of the nine-tap instances: 16 = 16 x 16 x 32 (default with fp32 activations: 8-16 % faster per layer,
+// tools/conv_ab.py), 32 = 32 x 32 x 16 (default with bf16 activations, where the 16 form's extra registers spill at
+// three waves per SIMD and the step is not matrix-bound).  BSED_IGEMM3N_SHAPE=16 / 32 forces one (A/B knob).
+static std::atomic<int> i3n_forced_shape{-1};
+extern "C" void bsed_igemm3n_set_shape(int shape) { i3n_forced_shape.store(shape == 16 || shape == 32 ? shape : 0); }
+static int i3n_shape16(int abf) {
+  int v = i3n_forced_shape.load();
+  if (v < 0) {
+    v = getenv("BSED_IGEMM3N_SHAPE") ? atoi(getenv("BSED_IGEMM3N_SHAPE")) : 0;
+    i3n_forced_shape.store(v);
+  }
+  return v ? v == 16 : !abf;
+}
 template <int NWN, int MW, int STATS, int PV, int NT9, int WPE, int ABF = 0>
 static int launch_i3n6(const Igemm3nParams& P, dim3 grid, size_t smem, hipStream_t s) {
+  if constexpr (NT9 == 1) {
+    if (i3n_shape16(ABF)) {
+      static BsedLdsOnce once16;
+      BSED_HIP(bsed_max_lds(once16, (const void*)igemm3n_kernel<NWN, MW, STATS, PV, NT9, WPE, ABF, 1>));
+      hipLaunchKernelGGL((igemm3n_kernel<NWN, MW, STATS, PV, NT9, WPE, ABF, 1>), grid, dim3(64 * NWN * MW), smem, s, P);
+      BSED_LAUNCH_CHECK();
+      return BSED_OK;
+    }
+  }
   static BsedLdsOnce once;
   BSED_HIP(bsed_max_lds(once, (const void*)igemm3n_kernel<NWN, MW, STATS, PV, NT9, WPE, ABF>));
   hipLaunchKernelGGL((igemm3n_kernel<NWN, MW, STATS, PV, NT9, WPE, ABF>), grid, dim3(64 * NWN * MW), smem, s, P);
@@ -354,7 +473,9 @@ static I3nPlan i3n_plan(int NP, int PP, int ntaps, int abf) {
   // BN = 128: three waves per SIMD (168 registers) only for the shape that fits them without spilling in the loop
   // (nine taps, patch of <= 192 positions): 339 vs 359 us on the 216 x 8 layer; two otherwise (PV = 9: 173 vs 192 us
   // on the 216 x 4 layer).  tools/conv_ab.py
-  if (NWN == 4) pl.WPE = wpe == 2 || wpe == 3 ? wpe : ((pl.PV == 6 && ntaps == 9) ? 3 : 2);
+  // (the 16 x 16 x 32 form needs ~185 registers at BN = 128: two waves per SIMD, where it is 8-12 % faster than the
+  //  32 x 32 x 16 form at three)
+  if (NWN == 4) pl.WPE = wpe == 2 || wpe == 3 ? wpe : ((pl.PV == 6 && ntaps == 9 && !i3n_shape16(abf)) ? 3 : 2);
   return pl;
 }
 
@@ -387,7 +508,9 @@ extern "C" int bsed_igemm3n_variant(const BsedIgemmDesc* d) {
   if (!d || d->TH <= 0 || d->TW <= 0) return -1;
   const int PP = (d->TW + 2 * d->hw) * (d->TH + 2 * d->hh);
   const I3nPlan pl = i3n_plan(d->NP, PP, d->ntaps, d->act_bf16);
-  return pl.NWN | pl.MW << 4 | pl.PV << 8 | pl.WPE << 12 | (d->act_bf16 ? 1 : 0) << 16;
+  // bit 17: the 16 x 16 x 32 MFMA form (nine-tap instances, template argument SH)
+  return pl.NWN | pl.MW << 4 | pl.PV << 8 | pl.WPE << 12 | (d->act_bf16 ? 1 : 0) << 16 |
+         ((d->ntaps == 9 && i3n_shape16(d->act_bf16)) ? 1 : 0) << 17;
 }
 
 extern "C" int bsed_igemm3n_stats_rows(const BsedIgemmDesc* d) {

@@ -468,6 +468,11 @@ def igemm3(inp, w3, N, NB, H, W, CIN, taps, bias=None, epilogue=EPI_PLAIN, valid
 IGEMM3N_WPE = {"wpe": None}   # A/B knob (set_igemm3n_wpe)
 
 
+def set_igemm3n_shape(shape):
+    """A/B knob: MFMA shape of the nine-tap N-split instances: 16 (16 x 16 x 32), 32 (32 x 32 x 16), 0 / None = default"""
+    L.lib().bsed_igemm3n_set_shape(_i(shape or 0))
+
+
 def set_igemm3n_wpe(wpe):
     """A/B knob of the BN = 128 build: 2 / 3 = built for that many waves per SIMD whatever the shape; + 8 = no raised
     wave priority outside the MFMA loop; 0 / None = default"""
@@ -505,7 +510,8 @@ def _igemm3n(inp, wtab, N, NB, H, W, CIN, taps, bias, epilogue, valid):
     stats = torch.empty((rows, 2, N), device=dev, dtype=torch.float32) if epilogue == EPI_STATS else None
     d.stats = _p(stats)
     _launch((f"igemm3n_kernel<{var & 15}, {(var >> 4) & 15}, {1 if epilogue == EPI_STATS else 0}, {(var >> 8) & 15}, "
-             f"{1 if len(taps) == 9 else 0}, {(var >> 12) & 15}, {(var >> 16) & 1}>", len(taps), CIN, N, H, W),
+             f"{1 if len(taps) == 9 else 0}, {(var >> 12) & 15}, {(var >> 16) & 1}" + (", 1>" if (var >> 17) & 1 else ">"),
+             len(taps), CIN, N, H, W),
             2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call("bsed_igemm3n", ctypes.byref(d), L.stream()),
             _esz(inp) * NB * H * W * (CIN + N))
     return out, stats

@@ -152,6 +152,9 @@ int bsed_igemm3n_stats_rows(const BsedIgemmDesc* desc /*host: NB, H, W, TH, TW, 
 int bsed_igemm3n_variant(const BsedIgemmDesc* desc);   /* NWN | MW << 4 | PV << 8 | WPE << 12 of the build */
 void bsed_igemm3n_set_wpe(int knob);  /* A/B knob: 2 / 3 = the BN = 128 build for that many waves per SIMD whatever the
                                        * shape, + 8 = no raised wave priority outside the MFMA loop, 0 = default */
+void bsed_igemm3n_set_shape(int shape); /* A/B knob: MFMA shape of the nine-tap instances, 16 = v_mfma_f32_16x16x32_bf16 (default with
+                                         * fp32 activations), 32 = v_mfma_f32_32x32x16_bf16 (default with bf16 activations, and
+                                         * bit-identical to bsed_igemm3); 0 = defaults / BSED_IGEMM3N_SHAPE */
 int bsed_igemm3s_auto_g(void);
 int bsed_igemm3s_auto_g2(int CIN, int N);   /* per shape (resident workgroups differ with the LDS footprint) */
 

@@ -1,8 +1,10 @@
 """The N-split split-fp32 convolution kernel (csrc/igemm3n.hip, round 3) against the slab kernel of rounds 1-2
 (csrc/igemm3.hip) and against a float64 reference: the layers are the reference's seven nn.Conv2d
 (/root/reference/src/models/CNN.py:46-47), the GRU input projections (src/models/RNN.py:7-16) and the
-discriminator's shapes.  Same accumulation order per output element => the output tensors are BIT-identical; the
-BatchNorm partial sums are summed in a different (fixed) order and compared in float64."""
+discriminator's shapes.  With 32 x 32 x 16 MFMAs the accumulation order per output element is the slab kernel's => the
+output tensors are BIT-identical; with 16 x 16 x 32 MFMAs (the default for fp32 activations: faster) a 32-channel chunk
+is summed inside ONE instruction instead of two, and the outputs agree to rounding (bar: 4e-6 of max|ref|, measured
+<= 1.5e-6).  The BatchNorm partial sums are summed in a different (fixed) order and compared in float64."""
 import os
 
 import numpy as np
@@ -30,12 +32,13 @@ SHAPES = [
 ]
 
 
-def _run(nsplit, x, w, bias, NB, H, W, CIN, N, taps, stats, valid, knob=0):
+def _run(nsplit, x, w, bias, NB, H, W, CIN, N, taps, stats, valid, knob=0, shape=0):
     from bsed_amd import ops
     os.environ["BSED_IGEMM3N"] = "1" if nsplit else "0"
     try:
         if nsplit:
             ops.set_igemm3n_wpe(knob)
+            ops.set_igemm3n_shape(shape)
         w3 = ops.pack_weight3(w, len(taps), CIN, N, CIN * N, N, 1)
         assert (w3.dim() == 6) == nsplit
         return ops.igemm3(x, w3, N, NB, H, W, CIN, taps, bias=bias, epilogue=ops.EPI_STATS if stats else ops.EPI_PLAIN,
@@ -44,6 +47,7 @@ def _run(nsplit, x, w, bias, NB, H, W, CIN, N, taps, stats, valid, knob=0):
         os.environ.pop("BSED_IGEMM3N", None)
         if nsplit:
             ops.set_igemm3n_wpe(0)
+            ops.set_igemm3n_shape(0)
 
 
 @pytest.mark.parametrize("NB,H,W,CIN,N,taps,stats,valid", SHAPES)
@@ -53,13 +57,18 @@ def test_nsplit_kernel_is_bit_identical_to_the_slab_kernel(NB, H, W, CIN, N, tap
     w = (torch.randn(len(taps), CIN, N, generator=g) / (len(taps) * CIN) ** 0.5).cuda()
     bias = torch.randn(N, generator=g).cuda()
     ref, ref_st = _run(False, x, w, bias, NB, H, W, CIN, N, taps, stats, valid)
-    for knob in (0, 2, 3, 8):
-        out, st = _run(True, x, w, bias, NB, H, W, CIN, N, taps, stats, valid, knob)
-        torch.cuda.synchronize()
-        assert torch.equal(out, ref), f"knob {knob}: max diff {float((out - ref).abs().max())}"
-        if stats:
-            a, b = st.double().sum(0).cpu().numpy(), ref_st.double().sum(0).cpu().numpy()
-            np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-4 * np.sqrt(NB * H * W))
+    for shape in (32, 16):
+        for knob in (0, 2, 3, 8):
+            out, st = _run(True, x, w, bias, NB, H, W, CIN, N, taps, stats, valid, knob, shape)
+            torch.cuda.synchronize()
+            if shape == 32 or len(taps) != 9:    # (the 16 x 16 x 32 form exists for the nine-tap instances only)
+                assert torch.equal(out, ref), f"shape {shape} knob {knob}: max diff {float((out - ref).abs().max())}"
+            else:
+                err = float((out - ref).abs().max())
+                assert err <= 4e-6 * float(ref.abs().max()), f"shape 16 knob {knob}: max diff {err}"
+            if stats:
+                a, b = st.double().sum(0).cpu().numpy(), ref_st.double().sum(0).cpu().numpy()
+                np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-4 * np.sqrt(NB * H * W))
 
 
 @pytest.mark.parametrize("NB,H,W,CIN,N,taps,stats,valid", SHAPES[:7])
