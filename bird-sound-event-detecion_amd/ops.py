@@ -510,7 +510,7 @@ def _igemm3n(inp, wtab, N, NB, H, W, CIN, taps, bias, epilogue, valid):
     stats = torch.empty((rows, 2, N), device=dev, dtype=torch.float32) if epilogue == EPI_STATS else None
     d.stats = _p(stats)
     _launch((f"igemm3n_kernel<{var & 15}, {(var >> 4) & 15}, {1 if epilogue == EPI_STATS else 0}, {(var >> 8) & 15}, "
-             f"{1 if len(taps) == 9 else 0}, {(var >> 12) & 15}, {(var >> 16) & 1}" + (", 1>" if (var >> 17) & 1 else ">"),
+             f"{1 if len(taps) == 9 else 0}, {(var >> 12) & 15}, {(var >> 16) & 1}, {(var >> 17) & 1}>",
              len(taps), CIN, N, H, W),
             2.0 * NB * H * W * len(taps) * CIN * N, lambda: L.call("bsed_igemm3n", ctypes.byref(d), L.stream()),
             _esz(inp) * NB * H * W * (CIN + N))
