@@ -413,7 +413,7 @@ void igemm3n_kernel(const Igemm3nParams P) {
 #endif
 }
 
-// MFMA shape of the nine-tap instances: 16 = 16 x 16 x 32 (default with fp32 activations: 8-16 % faster per layer,
+// MFMA shape of the nine-tap instances (and of the two-wave BN = 128 builds of the 1 - 4 tap forms): 16 = 16 x 16 x 32 (default with fp32 activations: 8-16 % faster per layer,
 // tools/conv_ab.py), 32 = 32 x 32 x 16 (default with bf16 activations, where the 16 form's extra registers spill at
 // three waves per SIMD and the step is not matrix-bound).  BSED_IGEMM3N_SHAPE=16 / 32 forces one (A/B knob).
 static std::atomic<int> i3n_forced_shape{-1};
@@ -428,7 +428,7 @@ static int i3n_shape16(int abf) {
 }
 template <int NWN, int MW, int STATS, int PV, int NT9, int WPE, int ABF = 0>
 static int launch_i3n6(const Igemm3nParams& P, dim3 grid, size_t smem, hipStream_t s) {
-  if constexpr (NT9 == 1) {
+  if constexpr (NT9 == 1 || (NWN == 4 && WPE == 2)) {   // (... and the two-wave BN = 128 builds of the 1 - 4 tap forms: GRU projections)
     if (i3n_shape16(ABF)) {
       static BsedLdsOnce once16;
       BSED_HIP(bsed_max_lds(once16, (const void*)igemm3n_kernel<NWN, MW, STATS, PV, NT9, WPE, ABF, 1>));
@@ -510,7 +510,7 @@ extern "C" int bsed_igemm3n_variant(const BsedIgemmDesc* d) {
   const I3nPlan pl = i3n_plan(d->NP, PP, d->ntaps, d->act_bf16);
   // bit 17: the 16 x 16 x 32 MFMA form (nine-tap instances, template argument SH)
   return pl.NWN | pl.MW << 4 | pl.PV << 8 | pl.WPE << 12 | (d->act_bf16 ? 1 : 0) << 16 |
-         ((d->ntaps == 9 && i3n_shape16(d->act_bf16)) ? 1 : 0) << 17;
+         (((d->ntaps == 9 || (pl.NWN == 4 && pl.WPE == 2)) && i3n_shape16(d->act_bf16)) ? 1 : 0) << 17;
 }
 
 extern "C" int bsed_igemm3n_stats_rows(const BsedIgemmDesc* d) {

